@@ -1,0 +1,71 @@
+// dfx_device.h — data layout in HBM shared by the host control code and the HIP kernels.
+//
+// Layout (all planes are float32, row pitch padded to 64 floats = 256 B so every row starts on a
+// cache-line boundary and 16-B vector accesses stay aligned):
+//
+//   frame slot f  : three pyramids  I, Ix, Iy     (Ix/Iy = centred gradient)
+//                   level s lives at element offset lvl_off[s] of the slot, pitch lvl_pitch[s]
+//   pair slot b   : NPLANES work planes sized for level 0, reused by every level with the
+//                   level's own pitch:  u[2 sets][2], p[2 sets][4], I1wx, I1wy, grad, rho_c
+//                   (ping-pong sets: a fused U+dual step reads one set and writes the other)
+//
+// A frame's pyramid is built once and serves as I1 of pair i and as I0 of pair i+step.
+#pragma once
+
+#include "tvl1_ctrl.h"
+
+#define DFX_LVL_MAX 16
+
+enum : int {
+    PL_U1_0 = 0, PL_U2_0, PL_U1_1, PL_U2_1,                // u sets 0/1
+    PL_P11_0, PL_P12_0, PL_P21_0, PL_P22_0,                // p set 0
+    PL_P11_1, PL_P12_1, PL_P21_1, PL_P22_1,                // p set 1
+    PL_I1WX, PL_I1WY, PL_GRAD, PL_RHOC,
+    PL_COUNT
+};
+
+struct PairDesc {
+    int frame_a; // frame slot of I0
+    int frame_b; // frame slot of I1
+};
+
+struct Tvl1Consts {
+    float l_t;   // (float)(lambda*theta)
+    float taut;  // (float)(tau/theta)
+    float theta; // (float)theta
+    float pad_;
+};
+
+// Everything a TVL1 kernel needs for one level; passed by value as the kernel argument.
+struct Tvl1LevelCtx {
+    // geometry of this level
+    int w, h, pitch;
+    // frame pyramids
+    const float *frame_I;   // base of frame slot 0, pyramid I
+    const float *frame_Ix;
+    const float *frame_Iy;
+    long long frame_stride; // elements between frame slots
+    long long lvl_off;      // element offset of this level inside a frame slot
+    // pair work planes
+    float *planes;          // base of pair slot 0
+    long long plane_stride; // elements between planes of one slot
+    long long slot_stride;  // elements between pair slots
+    // control
+    Tvl1State *state;       // [n_pairs]
+    const PairDesc *pairs;  // [n_pairs]
+    double *partials;       // [n_pairs][partials_stride]
+    int partials_stride;
+    int n_pairs;
+    Tvl1LoopCfg loop;
+    Tvl1Consts k;
+    double thr;             // scaledEpsilon of this level = eps^2 * (w*h)   (A.3)
+    int level;              // level index (0 = full resolution)
+    int *iters_out;         // [n_pairs][DFX_LVL_MAX][TVL1_MAX_WARPS] executed inner iterations
+    int *checks_out;        // [n_pairs][DFX_LVL_MAX][2] convergence sums evaluated, steps that did work
+    // completion signalling
+    unsigned int *level_done_count; // device counter of pairs that finished the level
+    volatile int *host_done_flag;   // pinned host word: set to done_token when every pair finished
+    int done_token;
+};
+
+static inline int dfx_round_up(int v, int m) { return (v + m - 1) / m * m; }

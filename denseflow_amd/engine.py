@@ -1,0 +1,273 @@
+"""ctypes binding of include/dfx.h.
+
+Mirrors the reference operator interface for the hot path: `FlowEngine.calc_optflows` takes the
+gray frames of one FlowBuffer and a step and returns the list of CV_32FC2-shaped flows exactly as
+DenseFlow::calc_optflows_imp does (/root/reference is not needed at run time; the behaviour is the
+one at src/denseflow_gpu.cpp:307-342).  Errors carry the reference's message texts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+_LIB_DIR = os.path.join(_HERE, "lib")
+_LIB = os.path.join(_LIB_DIR, "libdfx.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+DFX_MAX_LEVELS = 16
+DFX_MAX_WARPS = 16
+
+ALGO_TVL1, ALGO_FARN, ALGO_BROX = 0, 1, 2
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_NV_DISABLED, ERR_UNKNOWN_ALGO = range(7)
+
+
+class DfxError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+class DfxParams(C.Structure):
+    _fields_ = [
+        ("tvl1_tau", C.c_double),
+        ("tvl1_lambda", C.c_double),
+        ("tvl1_theta", C.c_double),
+        ("tvl1_nscales", C.c_int),
+        ("tvl1_warps", C.c_int),
+        ("tvl1_epsilon", C.c_double),
+        ("tvl1_iterations", C.c_int),
+        ("tvl1_scale_step", C.c_double),
+        ("farn_num_levels", C.c_int),
+        ("farn_pyr_scale", C.c_double),
+        ("farn_win_size", C.c_int),
+        ("farn_num_iters", C.c_int),
+        ("farn_poly_n", C.c_int),
+        ("farn_poly_sigma", C.c_double),
+        ("farn_flags", C.c_int),
+        ("brox_alpha", C.c_float),
+        ("brox_gamma", C.c_float),
+        ("brox_scale_factor", C.c_float),
+        ("brox_inner_iterations", C.c_int),
+        ("brox_outer_iterations", C.c_int),
+        ("brox_solver_iterations", C.c_int),
+        ("max_batch", C.c_int),
+        ("impl", C.c_int),
+        ("tvl1_fuse_k", C.c_int),
+    ]
+
+
+class DfxStats(C.Structure):
+    _fields_ = [
+        ("pairs", C.c_uint64),
+        ("kernel_launches", C.c_uint64),
+        ("noop_steps", C.c_uint64),
+        ("device_ms", C.c_double),
+        ("algorithmic_bytes", C.c_double),
+        ("levels", C.c_int),
+        ("level_w", C.c_int * DFX_MAX_LEVELS),
+        ("level_h", C.c_int * DFX_MAX_LEVELS),
+        ("tvl1_iters", (C.c_int * DFX_MAX_WARPS) * DFX_MAX_LEVELS),
+        ("tvl1_checks", C.c_int),
+        ("tvl1_total_iters", C.c_uint64),
+        ("tvl1_px_iters", C.c_double),
+    ]
+
+    def iters_table(self):
+        return [[self.tvl1_iters[s][w] for w in range(DFX_MAX_WARPS)] for s in range(self.levels)]
+
+
+# ------------------------------------------------------------------------------------------ build
+
+def library_path() -> str:
+    return _LIB
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into denseflow_amd/lib/libdfx.so (cross-compiles without a GPU)."""
+    srcs = sorted(
+        os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".hip") or f.endswith(".cpp")
+    )
+    deps = srcs + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")] + [
+        os.path.join(_ROOT, "include", "dfx.h")
+    ]
+    if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(d) for d in deps):
+        return _LIB
+    os.makedirs(_LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [
+        hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+        "-I" + os.path.join(_ROOT, "include"), "-o", _LIB,
+    ] + srcs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + r.stderr)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libdfx.so.  torch (if present) is imported first so both share one HIP runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise DfxError(ERR_NO_DEVICE, f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    try:  # torch bundles its own libamdhip64.so; loading it first makes the loader reuse that copy
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the library itself
+        pass
+    L = C.CDLL(_LIB)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    L.dfx_device_count.restype = i
+    L.dfx_default_params.argtypes = [C.POINTER(DfxParams)]
+    L.dfx_algo_from_name.argtypes = [C.c_char_p, C.POINTER(i)]
+    L.dfx_algo_from_name.restype = i
+    L.dfx_algo_error_message.argtypes = [i, C.c_char_p, C.c_char_p, sz]
+    L.dfx_algo_error_message.restype = C.c_char_p
+    L.dfx_create.argtypes = [C.POINTER(vp), i, i, i, i, C.POINTER(DfxParams)]
+    L.dfx_create.restype = i
+    L.dfx_calc.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    L.dfx_calc.restype = i
+    L.dfx_calc_batch.argtypes = [vp, C.POINTER(vp), sz, i, i, C.POINTER(vp), sz]
+    L.dfx_calc_batch.restype = i
+    L.dfx_calc_batch_device.argtypes = [vp, vp, sz, sz, i, i, vp, sz]
+    L.dfx_calc_batch_device.restype = i
+    L.dfx_get_stats.argtypes = [vp, C.POINTER(DfxStats)]
+    L.dfx_get_stats.restype = i
+    L.dfx_reset_stats.argtypes = [vp]
+    L.dfx_last_error.argtypes = [vp]
+    L.dfx_last_error.restype = C.c_char_p
+    L.dfx_destroy.argtypes = [vp]
+    L.dfx_device_malloc.argtypes = [vp, C.POINTER(vp), sz]
+    L.dfx_device_malloc.restype = i
+    L.dfx_device_free.argtypes = [vp, vp]
+    L.dfx_device_free.restype = i
+    L.dfx_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.dfx_memcpy_h2d.restype = i
+    L.dfx_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.dfx_memcpy_d2h.restype = i
+    L.dfx_host_alloc.argtypes = [C.POINTER(vp), sz]
+    L.dfx_host_alloc.restype = i
+    L.dfx_host_free.argtypes = [vp]
+    L.dfx_host_free.restype = i
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    return int(load_library().dfx_device_count())
+
+
+def algo_from_name(name: str) -> int:
+    """Map -a=<name>; raises with the reference's runtime_error texts (src/denseflow_gpu.cpp:296, :336)."""
+    L = load_library()
+    out = C.c_int(0)
+    rc = L.dfx_algo_from_name(name.encode(), C.byref(out))
+    if rc != OK:
+        buf = C.create_string_buffer(256)
+        L.dfx_algo_error_message(rc, name.encode(), buf, 256)
+        raise DfxError(rc, buf.value.decode())
+    return out.value
+
+
+def default_params() -> DfxParams:
+    p = DfxParams()
+    load_library().dfx_default_params(C.byref(p))
+    return p
+
+
+class FlowEngine:
+    """One handle = one device + one private stream set (not thread-safe), sized for width x height."""
+
+    def __init__(self, width: int, height: int, algorithm: str = "tvl1", device: int = 0,
+                 params: DfxParams | None = None, **knobs):
+        self._L = load_library()
+        self._h = C.c_void_p()
+        self.width, self.height = int(width), int(height)
+        self.algorithm = algorithm
+        algo = algo_from_name(algorithm)
+        if knobs:
+            if params is None:
+                params = default_params()
+            for k, v in knobs.items():
+                setattr(params, k, v)
+        rc = self._L.dfx_create(C.byref(self._h), int(device), algo, self.width, self.height,
+                                C.byref(params) if params is not None else None)
+        if rc != OK:
+            msg = self._L.dfx_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise DfxError(rc, msg or f"dfx_create failed with status {rc}")
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != OK:
+            raise DfxError(rc, self._L.dfx_last_error(self._h).decode() or f"dfx status {rc}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.dfx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- the hot path ------------------------------------------------------------------------
+    def calc(self, frame_a: np.ndarray, frame_b: np.ndarray) -> np.ndarray:
+        """alg->calc(a, b): one (H, W, 2) float32 flow, channel 0 = u (x), 1 = v (y)."""
+        a = np.ascontiguousarray(frame_a, dtype=np.uint8)
+        b = np.ascontiguousarray(frame_b, dtype=np.uint8)
+        if a.shape != (self.height, self.width) or b.shape != a.shape:
+            raise ValueError("frame shape does not match the engine")
+        out = np.empty((self.height, self.width, 2), dtype=np.float32)
+        self._check(self._L.dfx_calc(self._h, a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0],
+                                     out.ctypes.data, out.strides[0]))
+        return out
+
+    def calc_optflows(self, frames_gray, step: int):
+        """The loop of DenseFlow::calc_optflows_imp (src/denseflow_gpu.cpp:307-342) for one FlowBuffer."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
+        n = len(frames)
+        m = max(n - abs(step), 0)
+        flows = [np.empty((self.height, self.width, 2), dtype=np.float32) for _ in range(m)]
+        if m == 0:
+            return flows
+        for f in frames:
+            if f.shape != (self.height, self.width):
+                raise ValueError("frame shape does not match the engine")
+        fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        op = (C.c_void_p * m)(*[f.ctypes.data for f in flows])
+        self._check(self._L.dfx_calc_batch(self._h, fp, self.width, n, int(step), op, self.width * 8))
+        return flows
+
+    def calc_optflows_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,
+                             d_flows_ptr: int, flow_stride_floats: int):
+        """Frames and flows already resident in HBM (raw device pointers, e.g. torch .data_ptr())."""
+        self._check(self._L.dfx_calc_batch_device(self._h, d_frames_ptr, pitch, frame_stride, n_frames, int(step),
+                                                  d_flows_ptr, flow_stride_floats))
+
+    def stats(self) -> DfxStats:
+        s = DfxStats()
+        self._check(self._L.dfx_get_stats(self._h, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._L.dfx_reset_stats(self._h)

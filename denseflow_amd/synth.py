@@ -1,0 +1,121 @@
+"""Deterministic synthetic frame generator (SURVEY.md §8d "Synthetic frames").
+
+The reference ships no sample media (its .gitignore ignores *.mp4), so every config in
+BASELINE.json runs on frames minted here: a band-limited texture
+
+    T(x, y) = sum_{k<32} a_k * sin(2*pi*(fx_k*x + fy_k*y) + phi_k)
+
+with wavelengths log-uniform in [8, 128] px and a_k ~ wavelength**0.5, sampled analytically
+(no resampling blur) at coordinates that move by a translation (1.5, -0.75) px/frame plus a
+rotation of 0.05 deg/frame about the image centre.  Values are affinely mapped so frame 0
+spans [16, 240], rounded to uint8.  Ground-truth flow between two frames is exact.
+
+Only numpy is needed; `frames_torch` is an optional accelerator used by bench.py to mint
+long clips on the GPU quickly (values may differ from the numpy path by 1 LSB in rare pixels,
+which is irrelevant for throughput runs; parity tests always use the numpy path).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+N_COMPONENTS = 32
+TRANSLATION = (1.5, -0.75)  # px / frame
+ROTATION_DEG = 0.05  # deg / frame
+
+
+class SynthClip:
+    """A seeded clip description; frames are generated on demand."""
+
+    def __init__(self, width: int, height: int, seed: int):
+        self.width, self.height, self.seed = int(width), int(height), int(seed)
+        rng = np.random.default_rng(seed)
+        wavelength = np.exp(rng.uniform(math.log(8.0), math.log(128.0), N_COMPONENTS))
+        angle = rng.uniform(0.0, 2.0 * math.pi, N_COMPONENTS)
+        self.fx = np.cos(angle) / wavelength
+        self.fy = np.sin(angle) / wavelength
+        self.amp = wavelength ** 0.5
+        self.phase = rng.uniform(0.0, 2.0 * math.pi, N_COMPONENTS)
+        self._affine = None
+
+    # -- coordinates ---------------------------------------------------------------------
+    def _coords(self, t: float):
+        """Texture coordinates sampled by pixel (x, y) of frame t."""
+        w, h = self.width, self.height
+        cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
+        th = math.radians(ROTATION_DEG * t)
+        c, s = math.cos(th), math.sin(th)
+        x = np.arange(w, dtype=np.float64)[None, :] - cx
+        y = np.arange(h, dtype=np.float64)[:, None] - cy
+        X = c * x - s * y + cx + TRANSLATION[0] * t
+        Y = s * x + c * y + cy + TRANSLATION[1] * t
+        return X, Y
+
+    def _texture(self, X, Y):
+        out = np.zeros(np.broadcast(X, Y).shape, dtype=np.float64)
+        for k in range(N_COMPONENTS):
+            out += self.amp[k] * np.sin(2.0 * math.pi * (self.fx[k] * X + self.fy[k] * Y) + self.phase[k])
+        return out
+
+    def _get_affine(self):
+        if self._affine is None:
+            t0 = self._texture(*self._coords(0.0))
+            lo, hi = float(t0.min()), float(t0.max())
+            scale = (240.0 - 16.0) / (hi - lo)
+            self._affine = (scale, 16.0 - lo * scale)
+        return self._affine
+
+    # -- public --------------------------------------------------------------------------
+    def frame(self, t: int) -> np.ndarray:
+        """uint8 gray frame t, shape (H, W), C-contiguous."""
+        scale, offset = self._get_affine()
+        v = self._texture(*self._coords(float(t))) * scale + offset
+        return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+    def frames(self, n: int, start: int = 0):
+        return [self.frame(start + i) for i in range(n)]
+
+    def true_flow(self, t0: int, t1: int) -> np.ndarray:
+        """Exact flow (H, W, 2) taking pixels of frame t0 to their position in frame t1."""
+        w, h = self.width, self.height
+        cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
+        X, Y = self._coords(float(t0))  # texture point shown by each pixel of frame t0
+        X = np.broadcast_to(X, (h, w))
+        Y = np.broadcast_to(Y, (h, w))
+        th = math.radians(ROTATION_DEG * t1)
+        c, s = math.cos(th), math.sin(th)
+        xr = X - cx - TRANSLATION[0] * t1
+        yr = Y - cy - TRANSLATION[1] * t1
+        px = c * xr + s * yr + cx
+        py = -s * xr + c * yr + cy
+        gx = np.arange(w, dtype=np.float64)[None, :]
+        gy = np.arange(h, dtype=np.float64)[:, None]
+        return np.stack([px - gx, py - gy], axis=-1).astype(np.float32)
+
+    # -- optional GPU accelerator for long clips (bench only) ------------------------------
+    def frames_torch(self, n: int, device, start: int = 0):
+        """Return a uint8 torch tensor (n, H, W) on `device`, generated with float64 torch math."""
+        import torch
+
+        scale, offset = self._get_affine()
+        w, h = self.width, self.height
+        cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
+        x = torch.arange(w, dtype=torch.float64, device=device)[None, :] - cx
+        y = torch.arange(h, dtype=torch.float64, device=device)[:, None] - cy
+        fx = torch.tensor(self.fx, dtype=torch.float64, device=device)
+        fy = torch.tensor(self.fy, dtype=torch.float64, device=device)
+        amp = torch.tensor(self.amp, dtype=torch.float64, device=device)
+        ph = torch.tensor(self.phase, dtype=torch.float64, device=device)
+        out = torch.empty((n, h, w), dtype=torch.uint8, device=device)
+        for i in range(n):
+            t = float(start + i)
+            th = math.radians(ROTATION_DEG * t)
+            c, s = math.cos(th), math.sin(th)
+            X = c * x - s * y + cx + TRANSLATION[0] * t
+            Y = s * x + c * y + cy + TRANSLATION[1] * t
+            acc = torch.zeros((h, w), dtype=torch.float64, device=device)
+            for k in range(N_COMPONENTS):
+                acc += amp[k] * torch.sin(2.0 * math.pi * (fx[k] * X + fy[k] * Y) + ph[k])
+            out[i] = torch.clamp(torch.round(acc * scale + offset), 0, 255).to(torch.uint8)
+        return out

@@ -1,0 +1,157 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Importers allowed: tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg.  The product
+package (denseflow_amd/) never imports this module.  PARITY UNPINNED: see oracle_common.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+MAX_SCALES, MAX_WARPS, MAX_CHECKS = 16, 16, 8192
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (seconds)."""
+    if force:
+        subprocess.run(["make", "-C", _HERE, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", _HERE], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    return _LIB_PATH
+
+
+class Tvl1Params(C.Structure):
+    _fields_ = [
+        ("tau", C.c_double),
+        ("lambda_", C.c_double),
+        ("theta", C.c_double),
+        ("nscales", C.c_int),
+        ("warps", C.c_int),
+        ("epsilon", C.c_double),
+        ("iterations", C.c_int),
+        ("scale_step", C.c_double),
+        ("gamma", C.c_double),
+    ]
+
+
+class Tvl1Trace(C.Structure):
+    _fields_ = [
+        ("nscales", C.c_int),
+        ("w", C.c_int * MAX_SCALES),
+        ("h", C.c_int * MAX_SCALES),
+        ("iters", (C.c_int * MAX_WARPS) * MAX_SCALES),
+        ("n_checks", C.c_int),
+        ("chk_level", C.c_int * MAX_CHECKS),
+        ("chk_warp", C.c_int * MAX_CHECKS),
+        ("chk_n", C.c_int * MAX_CHECKS),
+        ("chk_err", C.c_double * MAX_CHECKS),
+    ]
+
+    def iters_table(self):
+        return [[self.iters[s][w] for w in range(MAX_WARPS)] for s in range(self.nscales)]
+
+    def checks(self):
+        n = min(self.n_checks, MAX_CHECKS)
+        return [(self.chk_level[i], self.chk_warp[i], self.chk_n[i], self.chk_err[i]) for i in range(n)]
+
+
+_lib = None
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    L.orc_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
+    L.orc_tvl1_calc.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, C.POINTER(Tvl1Params), _f32p,
+                                C.POINTER(Tvl1Trace)]
+    L.orc_tvl1_calc.restype = C.c_int
+    L.orc_resize_linear.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.orc_tvl1_centered_gradient.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p]
+    L.orc_tvl1_warp_backward.argtypes = [_f32p] * 6 + [C.c_int, C.c_int] + [_f32p] * 5
+    L.orc_tvl1_estimate_u.argtypes = [_f32p] * 10 + [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int]
+    L.orc_tvl1_estimate_u.restype = C.c_double
+    L.orc_tvl1_estimate_dual.argtypes = [_f32p] * 6 + [C.c_int, C.c_int, C.c_float]
+    L.orc_tvl1_proc_one_scale.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.POINTER(Tvl1Params),
+                                          C.c_int, C.POINTER(Tvl1Trace)]
+    if hasattr(L, "orc_farneback_calc"):
+        L.orc_farneback_default_params.argtypes = [C.POINTER(FarnebackParams)]
+        L.orc_farneback_calc.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int,
+                                         C.POINTER(FarnebackParams), _f32p]
+        L.orc_farneback_calc.restype = C.c_int
+    _lib = L
+    return L
+
+
+def tvl1_default_params() -> Tvl1Params:
+    p = Tvl1Params()
+    lib().orc_tvl1_default_params(C.byref(p))
+    return p
+
+
+def tvl1_calc(frame0: np.ndarray, frame1: np.ndarray, params: Tvl1Params | None = None, want_trace: bool = False):
+    """cv::cuda::OpticalFlowDual_TVL1::calc restatement. Returns flow (H,W,2) [, trace]."""
+    f0 = np.ascontiguousarray(frame0, dtype=np.uint8)
+    f1 = np.ascontiguousarray(frame1, dtype=np.uint8)
+    assert f0.shape == f1.shape and f0.ndim == 2
+    h, w = f0.shape
+    flow = np.empty((h, w, 2), dtype=np.float32)
+    trace = Tvl1Trace()
+    rc = lib().orc_tvl1_calc(f0, w, f1, w, w, h, C.byref(params) if params is not None else None, flow,
+                             C.byref(trace))
+    if rc != 0:
+        raise ValueError("orc_tvl1_calc rejected the parameters")
+    return (flow, trace) if want_trace else flow
+
+
+def resize_linear(src: np.ndarray, dw: int, dh: int, ifx: float, ify: float) -> np.ndarray:
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    sh, sw = src.shape
+    dst = np.empty((dh, dw), dtype=np.float32)
+    lib().orc_resize_linear(src, sw, sh, dst, dw, dh, ifx, ify)
+    return dst
+
+
+# ------------------------------------------------------------------------------ Farneback
+
+class FarnebackParams(C.Structure):
+    _fields_ = [
+        ("num_levels", C.c_int),
+        ("pyr_scale", C.c_double),
+        ("fast_pyramids", C.c_int),
+        ("win_size", C.c_int),
+        ("num_iters", C.c_int),
+        ("poly_n", C.c_int),
+        ("poly_sigma", C.c_double),
+        ("flags", C.c_int),
+    ]
+
+
+def farneback_default_params() -> FarnebackParams:
+    p = FarnebackParams()
+    lib().orc_farneback_default_params(C.byref(p))
+    return p
+
+
+def farneback_calc(frame0: np.ndarray, frame1: np.ndarray, params: FarnebackParams | None = None) -> np.ndarray:
+    f0 = np.ascontiguousarray(frame0, dtype=np.uint8)
+    f1 = np.ascontiguousarray(frame1, dtype=np.uint8)
+    assert f0.shape == f1.shape and f0.ndim == 2
+    h, w = f0.shape
+    flow = np.empty((h, w, 2), dtype=np.float32)
+    rc = lib().orc_farneback_calc(f0, w, f1, w, w, h, C.byref(params) if params is not None else None, flow)
+    if rc != 0:
+        raise ValueError("orc_farneback_calc rejected the parameters")
+    return flow

@@ -1,0 +1,55 @@
+// tests/ctrl_harness.cpp — TEST INFRASTRUCTURE.  Drives the device-side TVL1 control state machine
+// (denseflow_amd/csrc/tvl1_ctrl.h, the very header compiled into the kernels) on the CPU, using the
+// oracle's stage functions as the "kernels", so the segment/check/step bookkeeping can be compared
+// with the oracle's plain host loop for any fuse_k without a GPU.
+#include <cstring>
+#include <vector>
+
+#include "../denseflow_amd/csrc/tvl1_ctrl.h"
+#include "../oracle/tvl1_oracle.h"
+
+extern "C" int ctrl_replay_level(const float *I0, const float *I1, float *u1, float *u2, int W, int H, int warps,
+                                 int iterations, int fuse_k, double eps, double lambda, double theta, double tau,
+                                 int *iters_out, int *n_checks_out, int *steps_out) {
+    const size_t n = (size_t)W * H;
+    std::vector<float> buf(n * 11, 0.f);
+    float *I1x = buf.data(), *I1y = I1x + n, *I1w = I1y + n, *I1wx = I1w + n, *I1wy = I1wx + n, *grad = I1wy + n,
+          *rho = grad + n, *p11 = rho + n, *p12 = p11 + n, *p21 = p12 + n, *p22 = p21 + n;
+    orc_tvl1_centered_gradient(I1, W, H, I1x, I1y);
+    const float l_t = (float)(lambda * theta), taut = (float)(tau / theta), th = (float)theta;
+
+    Tvl1LoopCfg cfg{warps, iterations, fuse_k};
+    Tvl1State st;
+    std::memset(&st, 0, sizeof st);
+    st.phase = warps > 0 ? TVL1_PH_WARP : TVL1_PH_LEVEL_DONE;
+    st.thr = eps * eps * (double)(W * H);
+    st.next_check = TVL1_NO_CHECK;
+
+    int step_id = 0;
+    const int limit = warps * (iterations + 2) + 64;
+    for (; st.phase != TVL1_PH_LEVEL_DONE && step_id < limit; ++step_id) {
+        if (st.phase == TVL1_PH_WARP) {
+            orc_tvl1_warp_backward(I0, I1, I1x, I1y, u1, u2, W, H, I1w, I1wx, I1wy, grad, rho);
+            tvl1_begin_loop(st, cfg, step_id);
+            continue;
+        }
+        const Tvl1StepPlan p = tvl1_plan_step(st, cfg, step_id);
+        if (p.n_iters <= 0)
+            return -2;
+        double err = 0.0;
+        for (int k = 0; k < p.n_iters; ++k) {
+            const int check = p.do_check && (k == p.n_iters - 1);
+            err = orc_tvl1_estimate_u(I1wx, I1wy, grad, rho, p11, p12, p21, p22, u1, u2, W, H, l_t, th, check);
+            orc_tvl1_estimate_dual(u1, u2, p11, p12, p21, p22, W, H, taut);
+        }
+        if (p.is_last)
+            tvl1_end_segment(st, cfg, p, step_id, err);
+    }
+    if (st.phase != TVL1_PH_LEVEL_DONE)
+        return -1;
+    for (int w = 0; w < warps; ++w)
+        iters_out[w] = st.iters[w];
+    *n_checks_out = st.n_checks;
+    *steps_out = step_id;
+    return 0;
+}
