@@ -47,6 +47,7 @@ struct dfx_context {
     hipStream_t stream = nullptr;
     hipEvent_t ev_group[2] = {nullptr, nullptr};
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_lvl[DFX_LVL_MAX][2] = {};
 
     // pyramid geometry
     int nlevels = 0;
@@ -358,6 +359,7 @@ int run_tvl1_pairs(dfx_context *c, int nb, float *d_out, long long out_stride) {
         if (c->loop.warps > 0) {
             const int G = steps_per_group(c, s, nb);
             int step_id = 0;
+            HIPCHK(c, hipEventRecord(c->ev_lvl[s][0], c->stream));
             for (int g = 0;; ++g) {
                 for (int i = 0; i < G; ++i)
                     tvl1_launch_step(c->stream, x, step_id++, impl);
@@ -376,6 +378,7 @@ int run_tvl1_pairs(dfx_context *c, int nb, float *d_out, long long out_stride) {
                 }
             }
             c->launched_steps[s] = step_id;
+            HIPCHK(c, hipEventRecord(c->ev_lvl[s][1], c->stream));
         }
         if (s > 0) {
             const Level &D = c->lv[s - 1], &S = c->lv[s];
@@ -502,6 +505,11 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
         c->stats.device_ms += ms;
+        for (int s = 0; s < c->nlevels && c->loop.warps > 0; ++s) {
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev_lvl[s][0], c->ev_lvl[s][1]));
+            c->stats.step_ms += ms;
+            c->stats.step_launches += (uint64_t)c->launched_steps[s];
+        }
         account_tvl1(c, nb);
     }
     return DFX_OK;
@@ -592,6 +600,10 @@ int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_group[1], hipEventDisableTiming));
         HIPCHK(c, hipEventCreate(&c->ev_t0));
         HIPCHK(c, hipEventCreate(&c->ev_t1));
+        for (auto &e : c->ev_lvl) {
+            HIPCHK(c, hipEventCreate(&e[0]));
+            HIPCHK(c, hipEventCreate(&e[1]));
+        }
         if (algo == DFX_ALGO_TVL1)
             return create_tvl1(c);
         return fail(c, DFX_ERR_UNSUPPORTED, "algorithm not implemented yet");
@@ -678,6 +690,10 @@ void dfx_destroy(dfx_handle h) {
     for (auto &e : h->ev_group)
         if (e)
             (void)hipEventDestroy(e);
+    for (auto &e : h->ev_lvl)
+        for (auto &x : e)
+            if (x)
+                (void)hipEventDestroy(x);
     if (h->ev_t0)
         (void)hipEventDestroy(h->ev_t0);
     if (h->ev_t1)

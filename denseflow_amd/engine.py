@@ -68,6 +68,8 @@ class DfxStats(C.Structure):
         ("kernel_launches", C.c_uint64),
         ("noop_steps", C.c_uint64),
         ("device_ms", C.c_double),
+        ("step_ms", C.c_double),
+        ("step_launches", C.c_uint64),
         ("algorithmic_bytes", C.c_double),
         ("levels", C.c_int),
         ("level_w", C.c_int * DFX_MAX_LEVELS),
