@@ -269,7 +269,10 @@ int create_tvl1(dfx_context *c) {
 
     c->loop.warps = p.tvl1_warps;
     c->loop.iterations = p.tvl1_iterations;
-    c->loop.fuse_k = 1;
+    if (p.impl == 1)
+        c->loop.fuse_k = 1;
+    else
+        c->loop.fuse_k = std::max(1, std::min(p.tvl1_fuse_k > 0 ? p.tvl1_fuse_k : 4, tvl1_fused_max_k()));
     c->kc.l_t = (float)(p.tvl1_lambda * p.tvl1_theta);
     c->kc.taut = (float)(p.tvl1_tau / p.tvl1_theta);
     c->kc.theta = (float)p.tvl1_theta;
