@@ -340,11 +340,12 @@ int build_frames(dfx_context *c, const unsigned char *d_src, long long src_frame
 int steps_per_group(const dfx_context *c, int s, int nb) {
     if (c->group_override > 0)
         return c->group_override;
-    // aim at >= ~60 us of device work per group so the host stays ahead of the device
+    // aim at >= ~150 us of device work per group: the host stays ahead of the device and the event
+    // record between groups (~6 us of idle queue) stays below a few percent
     const double px = (double)c->lv[s].w * c->lv[s].h * nb;
     const double step_us = 2.0 + px * 64.0 * c->loop.fuse_k / 4.0e6; // bytes / (4 TB/s) in us
-    int g = (int)std::ceil(60.0 / step_us);
-    return std::max(4, std::min(32, g));
+    int g = (int)std::ceil(150.0 / step_us);
+    return std::max(6, std::min(16, g));
 }
 
 // Run the TVL1 pyramid for `nb` pairs whose descriptors are in c->h_pairs; flows go to d_out.
@@ -512,6 +513,8 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             HIPCHK(c, hipEventElapsedTime(&ms, c->ev_lvl[s][0], c->ev_lvl[s][1]));
             c->stats.step_ms += ms;
             c->stats.step_launches += (uint64_t)c->launched_steps[s];
+            c->stats.level_ms[s] += ms;
+            c->stats.level_launches[s] += (uint64_t)c->launched_steps[s];
         }
         account_tvl1(c, nb);
     }

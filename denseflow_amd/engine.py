@@ -70,6 +70,8 @@ class DfxStats(C.Structure):
         ("device_ms", C.c_double),
         ("step_ms", C.c_double),
         ("step_launches", C.c_uint64),
+        ("level_ms", C.c_double * DFX_MAX_LEVELS),
+        ("level_launches", C.c_uint64 * DFX_MAX_LEVELS),
         ("algorithmic_bytes", C.c_double),
         ("levels", C.c_int),
         ("level_w", C.c_int * DFX_MAX_LEVELS),

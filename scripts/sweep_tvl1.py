@@ -40,4 +40,6 @@ for cfg in configs:
     print(f"impl={impl} K={k} B={b}: {reps*(NF-1)/dt:8.1f} pairs/s  dev_ms/pair={st.device_ms/st.pairs:7.3f} step_ms/pair={st.step_ms/st.pairs:7.3f} "
           f"launches/pair={st.kernel_launches/st.pairs:7.1f} noop={st.noop_steps/max(st.step_launches,1):.3f} "
           f"alg_GB/s(step)={st.algorithmic_bytes/(st.step_ms*1e-3)/1e9:8.1f}  [{same}]", flush=True)
+    if os.environ.get("SWEEP_LEVELS"):
+        print("    per-level step ms/pair:", " ".join(f"L{l}={st.level_ms[l]/st.pairs:.3f}({st.level_launches[l]/ (st.pairs/ max(1,(b or 1))) :.0f} launches/batch, {st.level_ms[l]*1e3/max(st.level_launches[l],1):.1f}us/launch)" for l in range(st.levels)), flush=True)
     eng.close()
