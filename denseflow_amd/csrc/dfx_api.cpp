@@ -272,7 +272,7 @@ int create_tvl1(dfx_context *c) {
     if (p.impl == 1)
         c->loop.fuse_k = 1;
     else
-        c->loop.fuse_k = std::max(1, std::min(p.tvl1_fuse_k > 0 ? p.tvl1_fuse_k : 4, tvl1_fused_max_k()));
+        c->loop.fuse_k = std::max(1, std::min(p.tvl1_fuse_k > 0 ? p.tvl1_fuse_k : 4, tvl1_fused_max_k(p.tvl1_tile_h)));
     c->kc.l_t = (float)(p.tvl1_lambda * p.tvl1_theta);
     c->kc.taut = (float)(p.tvl1_tau / p.tvl1_theta);
     c->kc.theta = (float)p.tvl1_theta;
@@ -366,7 +366,7 @@ int run_tvl1_pairs(dfx_context *c, int nb, float *d_out, long long out_stride) {
             HIPCHK(c, hipEventRecord(c->ev_lvl[s][0], c->stream));
             for (int g = 0;; ++g) {
                 for (int i = 0; i < G; ++i)
-                    tvl1_launch_step(c->stream, x, step_id++, impl);
+                    tvl1_launch_step(c->stream, x, step_id++, impl, c->prm.tvl1_tile_h);
                 c->stats.kernel_launches += G;
                 HIPCHK(c, hipEventRecord(c->ev_group[g & 1], c->stream));
                 if (g >= 1) {

@@ -59,6 +59,7 @@ class DfxParams(C.Structure):
         ("max_batch", C.c_int),
         ("impl", C.c_int),
         ("tvl1_fuse_k", C.c_int),
+        ("tvl1_tile_h", C.c_int),
     ]
 
 

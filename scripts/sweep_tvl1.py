@@ -22,8 +22,10 @@ d_flows = torch.empty((NF - 1, H, W, 2), dtype=torch.float32, device=dev)
 torch.cuda.synchronize()
 ref = None
 for cfg in configs:
-    impl, k, b = (int(v) for v in cfg.split(":"))
-    eng = denseflow_amd.FlowEngine(W, H, "tvl1", impl=impl, tvl1_fuse_k=k, max_batch=b)
+    parts = [int(v) for v in cfg.split(":")]
+    impl, k, b = parts[:3]
+    th = parts[3] if len(parts) > 3 else 0
+    eng = denseflow_amd.FlowEngine(W, H, "tvl1", impl=impl, tvl1_fuse_k=k, max_batch=b, tvl1_tile_h=th)
     run = lambda: eng.calc_optflows_device(d_frames.data_ptr(), W, W * H, NF, 1, d_flows.data_ptr(), W * H * 2)
     run()
     eng.reset_stats()
@@ -37,7 +39,7 @@ for cfg in configs:
     same = "ref" if ref is None else ("bit-identical" if torch.equal(out, ref) else "DIFFERENT max|d|=%g" % float((out - ref).abs().max()))
     if ref is None:
         ref = out
-    print(f"impl={impl} K={k} B={b}: {reps*(NF-1)/dt:8.1f} pairs/s  dev_ms/pair={st.device_ms/st.pairs:7.3f} step_ms/pair={st.step_ms/st.pairs:7.3f} "
+    print(f"impl={impl} K={k} B={b} TH={th}: {reps*(NF-1)/dt:8.1f} pairs/s  dev_ms/pair={st.device_ms/st.pairs:7.3f} step_ms/pair={st.step_ms/st.pairs:7.3f} "
           f"launches/pair={st.kernel_launches/st.pairs:7.1f} noop={st.noop_steps/max(st.step_launches,1):.3f} "
           f"alg_GB/s(step)={st.algorithmic_bytes/(st.step_ms*1e-3)/1e9:8.1f}  [{same}]", flush=True)
     if os.environ.get("SWEEP_LEVELS"):
