@@ -1,0 +1,94 @@
+// dfx_internal.h — host-side plumbing shared by the C ABI (dfx_api.cpp) and the per-algorithm
+// engines (tvl1_engine.cpp, farneback_engine.cpp).  Nothing here crosses the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/dfx.h"
+#include "dfx_device.h"
+
+// An algorithm engine owns every device buffer of one handle.  The common driver (dfx_api.cpp)
+// walks a FlowBuffer in batches of `batch()` pairs, keeps the per-frame derived data (pyramids,
+// polynomial expansions) in a ring of frame slots so each frame is prepared once, and calls:
+//     build_frames  - prepare `n` new frames (u8 pixels already on the device) into the given slots
+//     run_pairs     - compute `nb` flows (pair -> frame-slot descriptors) into d_out
+//     account       - fold the finished batch into dfx_stats (after the stream is synchronised)
+struct dfx_context;
+
+class AlgoEngine {
+  public:
+    virtual ~AlgoEngine() {}
+    virtual int create() = 0;
+    virtual int batch() const = 0;
+    virtual int ensure_frame_slots(int need) = 0;
+    virtual int frame_slots() const = 0;
+    virtual int build_frames(const unsigned char *d_src, long long src_frame_stride, long long src_pitch, int n,
+                             const int *h_slots) = 0;
+    virtual int run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long long out_stride) = 0;
+    virtual int account(int nb) = 0; // reads per-batch event timers; stream is idle
+};
+
+struct dfx_context {
+    int device = 0;
+    dfx_algo algo = DFX_ALGO_TVL1;
+    int W = 0, H = 0;
+    dfx_params prm{};
+    std::string err;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+
+    AlgoEngine *engine = nullptr;
+
+    // staging shared by every engine
+    unsigned char *d_u8 = nullptr; // host-mode staging: u8_slots dense W*H frames
+    int u8_slots = 0;
+    float *d_flow_out = nullptr;   // host-mode staging: flow_slots dense H*W*2 flows
+    int flow_slots = 0;
+    std::vector<int> h_slots;      // slot id of each new frame of the current batch
+    std::vector<PairDesc> h_pairs; // descriptors of the current batch
+    long long frames_built = 0;    // frame ids [0, frames_built) of the current call are resident
+
+    dfx_stats stats{};
+};
+
+#define HIPCHK(ctx, call)                                                                                       \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            char buf_[512];                                                                                     \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,        \
+                     __LINE__);                                                                                 \
+            (ctx)->err = buf_;                                                                                  \
+            return DFX_ERR_HIP;                                                                                 \
+        }                                                                                                       \
+    } while (0)
+
+inline int dfx_fail(dfx_context *c, int code, const std::string &msg) {
+    if (c)
+        c->err = msg;
+    return code;
+}
+
+inline int dfx_cv_round(double v) { return (int)std::lrint(v); } // round-half-even
+
+template <class T> inline void dfx_free_dev(T *&p) {
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+    }
+}
+template <class T> inline void dfx_free_host(T *&p) {
+    if (p) {
+        (void)hipHostFree(p);
+        p = nullptr;
+    }
+}
+
+AlgoEngine *dfx_make_tvl1_engine(dfx_context *c);
+AlgoEngine *dfx_make_farneback_engine(dfx_context *c);

@@ -1,0 +1,61 @@
+// farneback_kernels.h — device data layout and host-callable launchers of the -a=farn kernels
+// (defined in farneback_kernels.hip).
+//
+// Layout in HBM (float32 planes, row pitch padded to 64 floats):
+//   frame slot f : for every pyramid level k the polynomial expansion R of that frame, 5 planes
+//                  (B.5) of pitch_k x h_k, at element offset r_off[k]; computed once per frame and
+//                  used as R1 of pair i and R0 of pair i+step
+//   pair slot b  : FARN_PL_COUNT planes sized for level 0: flow x/y (two sets: the level being
+//                  solved and the previous level it is up-sampled from) and M (two sets of 5 planes,
+//                  ping-pong: the fused iteration reads a 6-pixel halo of the old M while writing the new)
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "dfx_device.h"
+
+enum : int { FARN_PL_FX0 = 0, FARN_PL_FY0, FARN_PL_FX1, FARN_PL_FY1, FARN_PL_M0, FARN_PL_M1 = FARN_PL_M0 + 5,
+             FARN_PL_COUNT = FARN_PL_M1 + 5 };
+
+struct FarnPolyConsts { // B.3, non-negative halves
+    float g[8], xg[8], xxg[8];
+    float ig11, ig03, ig33, ig55;
+};
+
+struct FarnLevelGeom {
+    int w, h, pitch;
+    long long r_off; // element offset of this level's R (5 planes) inside a frame slot
+};
+
+struct FarnPairCtx {
+    FarnLevelGeom L;
+    const float *frame_R;   // base of frame slot 0
+    long long frame_stride; // elements between frame slots
+    float *planes;          // base of pair slot 0
+    long long plane_stride, slot_stride;
+    const PairDesc *pairs;
+    int n_pairs;
+};
+
+void farn_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long src_frame_stride, long long src_pitch,
+                           int n_frames, float *dst, long long dst_frame_stride, int w, int h, int pitch);
+// vertical Gaussian pass at the 2 source rows every destination row samples (B.4 + E.1 fused)
+void farn_launch_blur_v(hipStream_t s, const float *frames, long long frame_stride, int n_frames, int W, int H,
+                        int pitch0, int dst_h, float ify, const float *ker_half, int half, float *tmpv,
+                        long long tmpv_frame_stride);
+// horizontal Gaussian pass at the 2 source columns every destination pixel samples + bilinear resize
+void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_frame_stride, int n_frames, int W,
+                               int H, int pitch0, int dst_w, int dst_h, int dst_pitch, float ifx, float ify,
+                               const float *ker_half, int half, float *pyr, long long pyr_frame_stride);
+// polynomial expansion (B.5) of n_frames level images into their frame slots
+void farn_launch_polyexp(hipStream_t s, const float *pyr, long long pyr_frame_stride, int n_frames,
+                         const int *frame_slots, float *frame_R, long long frame_stride, FarnLevelGeom L,
+                         FarnPolyConsts pc);
+// flow(level k) = resize(flow(level k+1)) * (1/pyrScale), or zero at the coarsest level
+void farn_launch_init_flow(hipStream_t s, const FarnPairCtx &c, int cur_set, int prev_w, int prev_h, int prev_pitch,
+                           float ifx, float ify, float up, int zero);
+void farn_launch_update_matrices(hipStream_t s, const FarnPairCtx &c, int flow_set, int m_set);
+// boxFilter5 + updateFlow (+ updateMatrices) in one launch (B.8, B.9, B.7)
+void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, int m_src, int half, float box_inv,
+                           int do_matrices);
+void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride);

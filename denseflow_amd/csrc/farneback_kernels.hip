@@ -1,0 +1,416 @@
+// farneback_kernels.hip — hand-written gfx950 kernels for the -a=farn hot path.
+//
+// Replaces the CUDA kernels cv::cuda::FarnebackOpticalFlow::calc launches for the reference
+// (/root/reference/src/denseflow_gpu.cpp:329): gaussianBlur, resize, polynomialExpansion<5>,
+// updateMatrices, boxFilter5, updateFlow, convertTo, multiply, merge.
+//
+// What is restructured for MI355X (same arithmetic, same accumulation order, far fewer bytes):
+//   * upstream blurs the FULL-resolution frame at every pyramid level (up to 79 taps) and then
+//     bilinear-resizes it; here the separable blur is evaluated only at the rows/columns the resize
+//     samples (blur_v at 2 rows per destination row, blur_h at 2 columns per destination pixel);
+//   * boxFilter5 + updateFlow + updateMatrices are one launch per iteration: the 13x13 box sums are
+//     built in LDS from a halo tile, the 2x2 solve and the next M are computed in registers, so the
+//     box-filtered M is never written to HBM;
+//   * a frame's polynomial expansion is computed once and serves two pairs.
+// Compiled with -ffp-contract=off: every a*b+c is a rounded multiply then a rounded add, like the oracle.
+#include <hip/hip_runtime.h>
+
+#include "farneback_kernels.h"
+
+#define FARN_HALF_MAX 8 // box half-width supported by the fused iteration kernel (winSize <= 17)
+
+static inline dim3 grid64x4(int w, int h, int z) { return dim3((w + 63) / 64, (h + 3) / 4, z); }
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+
+__device__ __forceinline__ int reflect101_low(int x, int last) { return abs(x) % (last + 1); }
+__device__ __forceinline__ int reflect101_high(int x, int last) { return abs(last - abs(last - x)) % (last + 1); }
+__device__ __forceinline__ int reflect101(int x, int last) { return reflect101_low(reflect101_high(x, last), last); }
+
+__device__ __forceinline__ float *farn_plane(const FarnPairCtx &c, int pair, int plane) {
+    return c.planes + (long long)pair * c.slot_stride + (long long)plane * c.plane_stride;
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame preparation
+
+__global__ __launch_bounds__(256) void k_farn_u8_to_f32(const unsigned char *src, long long src_frame_stride,
+                                                        long long src_pitch, float *dst, long long dst_frame_stride,
+                                                        int w, int h, int pitch) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h)
+        return;
+    const int z = blockIdx.z;
+    dst[(long long)z * dst_frame_stride + (long long)y * pitch + x] =
+        (float)src[(long long)z * src_frame_stride + (long long)y * src_pitch + x];
+}
+
+// tmpv[z][2*dy + r][x] = vertical Gaussian pass (B.4) of frame z at source row (r ? y2r : y1r) of
+// destination row dy (E.1 row mapping), all full-resolution columns x.
+__global__ __launch_bounds__(256) void k_farn_blur_v(const float *frames, long long frame_stride, int W, int H,
+                                                     int pitch0, int dst_h, float ify, const float *ker, int half,
+                                                     float *tmpv, long long tmpv_frame_stride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int q = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || q >= 2 * dst_h)
+        return;
+    const int dy = q >> 1, r = q & 1;
+    const float sy = (float)dy * ify;
+    const int y1 = (int)floorf(sy);
+    const int yr = r ? min(y1 + 1, H - 1) : min(y1, H - 1);
+    const float *src = frames + (long long)blockIdx.z * frame_stride;
+    float v = src[(long long)yr * pitch0 + x] * ker[0];
+    for (int j = 1; j <= half; ++j) {
+        const float a = src[(long long)reflect101_low(yr - j, H - 1) * pitch0 + x];
+        const float b = src[(long long)reflect101_high(yr + j, H - 1) * pitch0 + x];
+        v = v + (a + b) * ker[j];
+    }
+    tmpv[(long long)blockIdx.z * tmpv_frame_stride + (long long)q * pitch0 + x] = v;
+}
+
+// pyr[z][dy][dx] = bilinear (E.1) of the blurred frame, the blur's horizontal pass (B.4) being
+// evaluated only at the two source columns this pixel samples.
+__global__ __launch_bounds__(256) void k_farn_blur_h_resize(const float *tmpv, long long tmpv_frame_stride, int W,
+                                                            int H, int pitch0, int dst_w, int dst_h, int dst_pitch,
+                                                            float ifx, float ify, const float *ker, int half,
+                                                            float *pyr, long long pyr_frame_stride) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= dst_w || dy >= dst_h)
+        return;
+    const float sx = (float)dx * ifx, sy = (float)dy * ify;
+    const int x1 = (int)floorf(sx), y1 = (int)floorf(sy);
+    const int x2 = x1 + 1, y2 = y1 + 1;
+    const int xc[2] = {min(x1, W - 1), min(x2, W - 1)};
+    const float *rows = tmpv + (long long)blockIdx.z * tmpv_frame_stride + (long long)(2 * dy) * pitch0;
+    float bl[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float *row = rows + (long long)r * pitch0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int cx = xc[k];
+            float res = row[cx] * ker[0];
+            for (int i = 1; i <= half; ++i)
+                res = res + (row[reflect101(cx - i, W - 1)] + row[reflect101(cx + i, W - 1)]) * ker[i];
+            bl[r][k] = res;
+        }
+    }
+    (void)H;
+    float out = 0.0f;
+    out = out + bl[0][0] * (((float)x2 - sx) * ((float)y2 - sy));
+    out = out + bl[0][1] * ((sx - (float)x1) * ((float)y2 - sy));
+    out = out + bl[1][0] * (((float)x2 - sx) * (sy - (float)y1));
+    out = out + bl[1][1] * ((sx - (float)x1) * (sy - (float)y1));
+    pyr[(long long)blockIdx.z * pyr_frame_stride + (long long)dy * dst_pitch + dx] = out;
+}
+
+// B.5: one workgroup = one row segment of 256 - 2*5 output pixels; vertical pass into LDS, then the
+// horizontal combinations.  (polyN = 5.)
+__global__ __launch_bounds__(256) void k_farn_polyexp(const float *pyr, long long pyr_frame_stride,
+                                                      const int *frame_slots, float *frame_R, long long frame_stride,
+                                                      FarnLevelGeom L, FarnPolyConsts pc) {
+    constexpr int N = 5;
+    __shared__ float row[3][256];
+    const int tx = threadIdx.x;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * (256 - 2 * N) + tx - N;
+    const float *src = pyr + (long long)blockIdx.z * pyr_frame_stride;
+    const int xw = min(max(x, 0), L.w - 1);
+    {
+        float a0 = src[(long long)y * L.pitch + xw] * pc.g[0];
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 1; k <= N; ++k) {
+            const float t0 = src[(long long)max(y - k, 0) * L.pitch + xw];
+            const float t1 = src[(long long)min(y + k, L.h - 1) * L.pitch + xw];
+            a0 = a0 + pc.g[k] * (t0 + t1);
+            a1 = a1 + pc.xg[k] * (t1 - t0);
+            a2 = a2 + pc.xxg[k] * (t0 + t1);
+        }
+        row[0][tx] = a0;
+        row[1][tx] = a1;
+        row[2][tx] = a2;
+    }
+    __syncthreads();
+    if (tx >= N && tx + N < 256 && x < L.w) {
+        float b1 = pc.g[0] * row[0][tx];
+        float b3 = pc.g[0] * row[1][tx];
+        float b5 = pc.g[0] * row[2][tx];
+        float b2 = 0, b4 = 0, b6 = 0;
+#pragma unroll
+        for (int k = 1; k <= N; ++k) {
+            b1 = b1 + (row[0][tx + k] + row[0][tx - k]) * pc.g[k];
+            b4 = b4 + (row[0][tx + k] + row[0][tx - k]) * pc.xxg[k];
+            b2 = b2 + (row[0][tx + k] - row[0][tx - k]) * pc.xg[k];
+            b3 = b3 + (row[1][tx + k] + row[1][tx - k]) * pc.g[k];
+            b6 = b6 + (row[1][tx + k] - row[1][tx - k]) * pc.xg[k];
+            b5 = b5 + (row[2][tx + k] + row[2][tx - k]) * pc.g[k];
+        }
+        const long long ps = (long long)L.pitch * L.h;
+        float *R = frame_R + (long long)frame_slots[blockIdx.z] * frame_stride + L.r_off + (long long)y * L.pitch + x;
+        R[0] = b3 * pc.ig11;
+        R[ps] = b2 * pc.ig11;
+        R[2 * ps] = b1 * pc.ig03 + b5 * pc.ig33;
+        R[3 * ps] = b1 * pc.ig03 + b4 * pc.ig33;
+        R[4 * ps] = b6 * pc.ig55;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-pair kernels
+
+__device__ __forceinline__ float resize_linear_px_f(const float *src, int sw, int sh, int spitch, int dx, int dy,
+                                                    float ifx, float ify) {
+    const float sx = (float)dx * ifx;
+    const float sy = (float)dy * ify;
+    const int x1 = (int)floorf(sx), y1 = (int)floorf(sy);
+    const int x2 = x1 + 1, y2 = y1 + 1;
+    const int x2r = min(x2, sw - 1), y2r = min(y2, sh - 1);
+    const int x1r = min(x1, sw - 1), y1r = min(y1, sh - 1);
+    float out = 0.0f;
+    out = out + src[(long long)y1r * spitch + x1r] * (((float)x2 - sx) * ((float)y2 - sy));
+    out = out + src[(long long)y1r * spitch + x2r] * ((sx - (float)x1) * ((float)y2 - sy));
+    out = out + src[(long long)y2r * spitch + x1r] * (((float)x2 - sx) * (sy - (float)y1));
+    out = out + src[(long long)y2r * spitch + x2r] * ((sx - (float)x1) * (sy - (float)y1));
+    return out;
+}
+
+__global__ __launch_bounds__(256) void k_farn_init_flow(FarnPairCtx c, int cur_set, int prev_w, int prev_h,
+                                                        int prev_pitch, float ifx, float ify, float up, int zero) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.L.w || y >= c.L.h)
+        return;
+    const int b = blockIdx.z;
+    const long long o = (long long)y * c.L.pitch + x;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        float *dst = farn_plane(c, b, FARN_PL_FX0 + 2 * cur_set + k);
+        if (zero) {
+            dst[o] = 0.0f;
+        } else {
+            const float *src = farn_plane(c, b, FARN_PL_FX0 + 2 * (cur_set ^ 1) + k);
+            dst[o] = resize_linear_px_f(src, prev_w, prev_h, prev_pitch, x, y, ifx, ify) * up;
+        }
+    }
+}
+
+__constant__ float c_farn_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
+
+// B.7 for one pixel.  R0/R1 point at plane 0 of the level inside the two frame slots.
+__device__ __forceinline__ void update_matrices_px(const float *R0, const float *R1, int w, int h, int pitch, int x,
+                                                   int y, float dx, float dy, float (&M)[5]) {
+    const long long ps = (long long)pitch * h;
+    const long long o = (long long)y * pitch + x;
+    float fx = (float)x + dx;
+    float fy = (float)y + dy;
+    const int x1 = (int)floorf(fx);
+    const int y1 = (int)floorf(fy);
+    fx -= (float)x1;
+    fy -= (float)y1;
+    float r2, r3, r4, r5, r6;
+    if (x1 >= 0 && y1 >= 0 && x1 < w - 1 && y1 < h - 1) {
+        const float a00 = (1.f - fx) * (1.f - fy);
+        const float a01 = fx * (1.f - fy);
+        const float a10 = (1.f - fx) * fy;
+        const float a11 = fx * fy;
+        const long long q = (long long)y1 * pitch + x1;
+        float v[5];
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const float *Rp = R1 + p * ps;
+            v[p] = ((a00 * Rp[q] + a01 * Rp[q + 1]) + a10 * Rp[q + pitch]) + a11 * Rp[q + pitch + 1];
+        }
+        r2 = v[0];
+        r3 = v[1];
+        r4 = (R0[2 * ps + o] + v[2]) * 0.5f;
+        r5 = (R0[3 * ps + o] + v[3]) * 0.5f;
+        r6 = (R0[4 * ps + o] + v[4]) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * ps + o];
+        r5 = R0[3 * ps + o];
+        r6 = R0[4 * ps + o] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[ps + o] - r3) * 0.5f;
+    r2 = r2 + (r4 * dy + r6 * dx); // r2 += r4*dy + r6*dx
+    r3 = r3 + (r6 * dy + r5 * dx);
+    float scale = c_farn_border[min(x, 5)] * c_farn_border[min(y, 5)];
+    scale = scale * c_farn_border[min(w - x - 1, 5)];
+    scale = scale * c_farn_border[min(h - y - 1, 5)];
+    r2 *= scale;
+    r3 *= scale;
+    r4 *= scale;
+    r5 *= scale;
+    r6 *= scale;
+    M[0] = r4 * r4 + r6 * r6;
+    M[1] = (r4 + r5) * r6;
+    M[2] = r5 * r5 + r6 * r6;
+    M[3] = r4 * r2 + r6 * r3;
+    M[4] = r6 * r2 + r5 * r3;
+}
+
+__global__ __launch_bounds__(256) void k_farn_update_matrices(FarnPairCtx c, int flow_set, int m_set) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.L.w || y >= c.L.h)
+        return;
+    const int b = blockIdx.z;
+    const PairDesc pd = c.pairs[b];
+    const float *R0 = c.frame_R + (long long)pd.frame_a * c.frame_stride + c.L.r_off;
+    const float *R1 = c.frame_R + (long long)pd.frame_b * c.frame_stride + c.L.r_off;
+    const long long o = (long long)y * c.L.pitch + x;
+    const float dx = farn_plane(c, b, FARN_PL_FX0 + 2 * flow_set)[o];
+    const float dy = farn_plane(c, b, FARN_PL_FY0 + 2 * flow_set)[o];
+    float M[5];
+    update_matrices_px(R0, R1, c.L.w, c.L.h, c.L.pitch, x, y, dx, dy, M);
+#pragma unroll
+    for (int p = 0; p < 5; ++p)
+        farn_plane(c, b, (m_set ? FARN_PL_M1 : FARN_PL_M0) + p)[o] = M[p];
+}
+
+// One Farneback iteration in one launch: 13x13 box filter of the 5 M planes (B.8: vertical sums, then
+// horizontal sums, in upstream's order, replicate border), the 2x2 solve (B.9) and, unless this is
+// the last iteration, the next M (B.7) written to the other M set.
+// Tile: 64 x 16 output pixels per workgroup, 4 rows per thread; LDS: (64+2h) x (16+2h) input tile and
+// 16 x (64+2h) vertical sums, reused for the 5 planes.
+__global__ __launch_bounds__(256) void k_farn_iteration(FarnPairCtx c, int flow_set, int m_src, int half,
+                                                        float box_inv, int do_matrices) {
+    constexpr int TW = 64, TH = 16, HM = FARN_HALF_MAX;
+    __shared__ float tile[TH + 2 * HM][TW + 2 * HM];
+    __shared__ float vs[TH][TW + 2 * HM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int w = c.L.w, h = c.L.h, pitch = c.L.pitch;
+    const int twp = TW + 2 * half, thp = TH + 2 * half;
+
+    float m[5][4];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const float *Mp = farn_plane(c, b, (m_src ? FARN_PL_M1 : FARN_PL_M0) + p);
+        for (int ty = wave; ty < thp; ty += 4) {
+            const long long ro = (long long)min(max(y0 - half + ty, 0), h - 1) * pitch;
+            for (int tx = lane; tx < twp; tx += 64)
+                tile[ty][tx] = Mp[ro + min(max(x0 - half + tx, 0), w - 1)];
+        }
+        __syncthreads();
+        for (int r = wave; r < TH; r += 4) {
+            for (int tx = lane; tx < twp; tx += 64) {
+                float v = tile[r + half][tx];
+                for (int j = 1; j <= half; ++j)
+                    v = v + (tile[r + half - j][tx] + tile[r + half + j][tx]);
+                vs[r][tx] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wave * 4 + i;
+            float res = vs[r][lane + half];
+            for (int k = 1; k <= half; ++k)
+                res = res + (vs[r][lane + half - k] + vs[r][lane + half + k]);
+            m[p][i] = res * box_inv;
+        }
+        __syncthreads();
+    }
+
+    const int x = x0 + lane;
+    if (x >= w)
+        return;
+    const PairDesc pd = c.pairs[b];
+    const float *R0 = c.frame_R + (long long)pd.frame_a * c.frame_stride + c.L.r_off;
+    const float *R1 = c.frame_R + (long long)pd.frame_b * c.frame_stride + c.L.r_off;
+    float *FX = farn_plane(c, b, FARN_PL_FX0 + 2 * flow_set), *FY = farn_plane(c, b, FARN_PL_FY0 + 2 * flow_set);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = y0 + wave * 4 + i;
+        if (y >= h)
+            break;
+        const long long o = (long long)y * pitch + x;
+        const float g11 = m[0][i], g12 = m[1][i], g22 = m[2][i], h1 = m[3][i], h2 = m[4][i];
+        const float detInv = 1.f / ((g11 * g22 - g12 * g12) + 1e-3f);
+        const float fx = (g11 * h2 - g12 * h1) * detInv;
+        const float fy = (g22 * h1 - g12 * h2) * detInv;
+        FX[o] = fx;
+        FY[o] = fy;
+        if (do_matrices) {
+            float M[5];
+            update_matrices_px(R0, R1, w, h, pitch, x, y, fx, fy, M);
+#pragma unroll
+            for (int p = 0; p < 5; ++p)
+                farn_plane(c, b, (m_src ? FARN_PL_M0 : FARN_PL_M1) + p)[o] = M[p];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_farn_merge(FarnPairCtx c, int flow_set, float *out, long long out_stride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.L.w || y >= c.L.h)
+        return;
+    const int b = blockIdx.z;
+    const long long o = (long long)y * c.L.pitch + x;
+    float2 v;
+    v.x = farn_plane(c, b, FARN_PL_FX0 + 2 * flow_set)[o];
+    v.y = farn_plane(c, b, FARN_PL_FY0 + 2 * flow_set)[o];
+    reinterpret_cast<float2 *>(out + (long long)b * out_stride)[(long long)y * c.L.w + x] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+
+void farn_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long src_frame_stride, long long src_pitch,
+                           int n_frames, float *dst, long long dst_frame_stride, int w, int h, int pitch) {
+    hipLaunchKernelGGL(k_farn_u8_to_f32, grid64x4(w, h, n_frames), dim3(256), 0, s, src, src_frame_stride, src_pitch,
+                       dst, dst_frame_stride, w, h, pitch);
+}
+
+void farn_launch_blur_v(hipStream_t s, const float *frames, long long frame_stride, int n_frames, int W, int H,
+                        int pitch0, int dst_h, float ify, const float *ker_half, int half, float *tmpv,
+                        long long tmpv_frame_stride) {
+    hipLaunchKernelGGL(k_farn_blur_v, grid64x4(W, 2 * dst_h, n_frames), dim3(256), 0, s, frames, frame_stride, W, H,
+                       pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride);
+}
+
+void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_frame_stride, int n_frames, int W,
+                               int H, int pitch0, int dst_w, int dst_h, int dst_pitch, float ifx, float ify,
+                               const float *ker_half, int half, float *pyr, long long pyr_frame_stride) {
+    hipLaunchKernelGGL(k_farn_blur_h_resize, grid64x4(dst_w, dst_h, n_frames), dim3(256), 0, s, tmpv,
+                       tmpv_frame_stride, W, H, pitch0, dst_w, dst_h, dst_pitch, ifx, ify, ker_half, half, pyr,
+                       pyr_frame_stride);
+}
+
+void farn_launch_polyexp(hipStream_t s, const float *pyr, long long pyr_frame_stride, int n_frames,
+                         const int *frame_slots, float *frame_R, long long frame_stride, FarnLevelGeom L,
+                         FarnPolyConsts pc) {
+    const dim3 grid((L.w + 245) / 246, L.h, n_frames);
+    hipLaunchKernelGGL(k_farn_polyexp, grid, dim3(256), 0, s, pyr, pyr_frame_stride, frame_slots, frame_R,
+                       frame_stride, L, pc);
+}
+
+void farn_launch_init_flow(hipStream_t s, const FarnPairCtx &c, int cur_set, int prev_w, int prev_h, int prev_pitch,
+                           float ifx, float ify, float up, int zero) {
+    hipLaunchKernelGGL(k_farn_init_flow, grid64x4(c.L.w, c.L.h, c.n_pairs), dim3(256), 0, s, c, cur_set, prev_w,
+                       prev_h, prev_pitch, ifx, ify, up, zero);
+}
+
+void farn_launch_update_matrices(hipStream_t s, const FarnPairCtx &c, int flow_set, int m_set) {
+    hipLaunchKernelGGL(k_farn_update_matrices, grid64x4(c.L.w, c.L.h, c.n_pairs), dim3(256), 0, s, c, flow_set,
+                       m_set);
+}
+
+void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, int m_src, int half, float box_inv,
+                           int do_matrices) {
+    const dim3 grid((c.L.w + 63) / 64, (c.L.h + 15) / 16, c.n_pairs);
+    hipLaunchKernelGGL(k_farn_iteration, grid, dim3(256), 0, s, c, flow_set, m_src, half, box_inv, do_matrices);
+}
+
+void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride) {
+    hipLaunchKernelGGL(k_farn_merge, grid64x4(c.L.w, c.L.h, c.n_pairs), dim3(256), 0, s, c, flow_set, out,
+                       out_stride);
+}

@@ -74,6 +74,7 @@ class DfxStats(C.Structure):
         ("level_ms", C.c_double * DFX_MAX_LEVELS),
         ("level_launches", C.c_uint64 * DFX_MAX_LEVELS),
         ("algorithmic_bytes", C.c_double),
+        ("step_algorithmic_bytes", C.c_double),
         ("levels", C.c_int),
         ("level_w", C.c_int * DFX_MAX_LEVELS),
         ("level_h", C.c_int * DFX_MAX_LEVELS),

@@ -312,11 +312,11 @@ void orc_farneback_update_matrices(const float *flowx, const float *flowy, const
             r3 = (R0[plane + o] - r3) * 0.5f;
             {
                 const float a = r4 * dy, b = r6 * dx;
-                r2 = (r2 + a) + b; /* r2 += r4*dy + r6*dx  ==  r2 + (r4*dy + r6*dx) */
+                r2 = r2 + (a + b); /* r2 += r4*dy + r6*dx : the right-hand side is summed first */
             }
             {
                 const float a = r6 * dy, b = r5 * dx;
-                r3 = (r3 + a) + b;
+                r3 = r3 + (a + b);
             }
             float scale = c_border[orc_imin(x, BORDER_SIZE)] * c_border[orc_imin(y, BORDER_SIZE)];
             scale = scale * c_border[orc_imin(W - x - 1, BORDER_SIZE)];

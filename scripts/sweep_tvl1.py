@@ -14,6 +14,7 @@ import denseflow_amd  # noqa: E402
 from denseflow_amd.synth import SynthClip  # noqa: E402
 
 W, H, NF = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (1920, 1080, 33)))
+ALGO = os.environ.get("ALGO", "tvl1")
 configs = os.environ.get("SWEEP", "0:4:0,0:4:4,0:2:4,0:6:4,0:8:4,0:4:8,0:4:1,1:1:2").split(",")
 dev = torch.device("cuda", 0)
 clip = SynthClip(W, H, 2)
@@ -25,7 +26,7 @@ for cfg in configs:
     parts = [int(v) for v in cfg.split(":")]
     impl, k, b = parts[:3]
     th = parts[3] if len(parts) > 3 else 0
-    eng = denseflow_amd.FlowEngine(W, H, "tvl1", impl=impl, tvl1_fuse_k=k, max_batch=b, tvl1_tile_h=th)
+    eng = denseflow_amd.FlowEngine(W, H, ALGO, impl=impl, tvl1_fuse_k=k, max_batch=b, tvl1_tile_h=th)
     run = lambda: eng.calc_optflows_device(d_frames.data_ptr(), W, W * H, NF, 1, d_flows.data_ptr(), W * H * 2)
     run()
     eng.reset_stats()
@@ -41,7 +42,7 @@ for cfg in configs:
         ref = out
     print(f"impl={impl} K={k} B={b} TH={th}: {reps*(NF-1)/dt:8.1f} pairs/s  dev_ms/pair={st.device_ms/st.pairs:7.3f} step_ms/pair={st.step_ms/st.pairs:7.3f} "
           f"launches/pair={st.kernel_launches/st.pairs:7.1f} noop={st.noop_steps/max(st.step_launches,1):.3f} "
-          f"alg_GB/s(step)={st.algorithmic_bytes/(st.step_ms*1e-3)/1e9:8.1f}  [{same}]", flush=True)
+          f"alg_GB/s(step)={st.step_algorithmic_bytes/(st.step_ms*1e-3)/1e9:8.1f}  [{same}]", flush=True)
     if os.environ.get("SWEEP_LEVELS"):
         print("    per-level step ms/pair:", " ".join(f"L{l}={st.level_ms[l]/st.pairs:.3f}({st.level_launches[l]/ (st.pairs/ max(1,(b or 1))) :.0f} launches/batch, {st.level_ms[l]*1e3/max(st.level_launches[l],1):.1f}us/launch)" for l in range(st.levels)), flush=True)
     eng.close()

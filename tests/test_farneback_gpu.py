@@ -1,0 +1,104 @@
+"""GPU parity tests for -a=farn: the HIP path (through the C ABI) against the CPU oracle, the
+committed golden vectors and size-independent properties at BASELINE.json's full size.
+Tolerance from BASELINE.json north_star: <= 1e-3 max-abs on u/v before bounding.  The device runs
+the oracle's arithmetic in the oracle's order, so an exact-equality test is included as well."""
+import os
+
+import numpy as np
+import pytest
+
+from denseflow_amd.synth import SynthClip
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("w,h,seed,dt", [(64, 48, 3, 1), (97, 61, 9, 1), (224, 224, 1, 1), (300, 200, 6, 2),
+                                         (33, 40, 2, 1), (640, 360, 4, 1)])
+def test_single_pair_matches_oracle(dfx, oracle, w, h, seed, dt):
+    clip = SynthClip(w, h, seed)
+    f0, f1 = clip.frame(0), clip.frame(dt)
+    ref = oracle.farneback_calc(f0, f1)
+    with dfx.FlowEngine(w, h, "farn") as eng:
+        out = eng.calc(f0, f1)
+    assert np.max(np.abs(out - ref)) <= TOL
+
+
+@pytest.mark.parametrize("w,h,seed", [(224, 224, 1), (130, 97, 5)])
+def test_bit_exact_with_oracle(dfx, oracle, w, h, seed):
+    clip = SynthClip(w, h, seed)
+    f0, f1 = clip.frame(0), clip.frame(1)
+    ref = oracle.farneback_calc(f0, f1)
+    with dfx.FlowEngine(w, h, "farn") as eng:
+        out = eng.calc(f0, f1)
+    assert np.array_equal(out, ref), f"max-abs {np.max(np.abs(out - ref))}"
+
+
+def test_golden_vectors(dfx):
+    g = np.load(os.path.join(GOLDEN, "farneback_golden.npz"))
+    for key in [k[:-5] for k in g.files if k.endswith("_flow")]:
+        w, h, seed, t0, t1 = [int(v) for v in g[key + "_meta"]]
+        clip = SynthClip(w, h, seed)
+        with dfx.FlowEngine(w, h, "farn") as eng:
+            out = eng.calc(clip.frame(t0), clip.frame(t1))
+        assert np.max(np.abs(out - g[key + "_flow"])) <= TOL, key
+
+
+@pytest.mark.parametrize("step", [1, -2])
+def test_flowbuffer_pair_selection_and_batching(dfx, oracle, step):
+    w, h, n = 96, 80, 7
+    frames = SynthClip(w, h, 21).frames(n)
+    with dfx.FlowEngine(w, h, "farn", max_batch=3) as eng:
+        flows = eng.calc_optflows(frames, step)
+    m = n - abs(step)
+    assert len(flows) == m
+    for i in range(m):
+        a = i if step > 0 else i - step
+        b = i + step if step > 0 else i
+        assert np.max(np.abs(flows[i] - oracle.farneback_calc(frames[a], frames[b]))) <= TOL, (step, i)
+
+
+def test_parameters_and_unsupported_variants(dfx, oracle):
+    w, h = 128, 96
+    clip = SynthClip(w, h, 13)
+    f0, f1 = clip.frame(0), clip.frame(1)
+    p = oracle.farneback_default_params()
+    p.num_levels, p.win_size, p.num_iters = 2, 9, 4
+    ref = oracle.farneback_calc(f0, f1, p)
+    with dfx.FlowEngine(w, h, "farn", farn_num_levels=2, farn_win_size=9, farn_num_iters=4) as eng:
+        out = eng.calc(f0, f1)
+    assert np.max(np.abs(out - ref)) <= TOL
+    with pytest.raises(dfx.DfxError) as e:
+        dfx.FlowEngine(w, h, "farn", farn_flags=256)  # OPTFLOW_FARNEBACK_GAUSSIAN: denseflow never sets it
+    assert e.value.status == 4
+
+
+def test_full_size_1080p(dfx, oracle):
+    w, h = 1920, 1080
+    clip = SynthClip(w, h, 2)
+    f0, f1 = clip.frame(0), clip.frame(1)
+    with dfx.FlowEngine(w, h, "farn") as eng:
+        out = eng.calc(f0, f1)
+        again = eng.calc(f0, f1)
+    assert np.array_equal(out, again)
+    ref = oracle.farneback_calc(f0, f1)
+    assert np.max(np.abs(out - ref)) <= TOL
+    gt = clip.true_flow(0, 1)
+    assert np.abs(out - gt)[64:-64, 64:-64].mean() < 0.1
+
+
+def test_device_resident_entry_point(dfx):
+    import torch
+
+    w, h, n = 224, 160, 6
+    frames = SynthClip(w, h, 77).frames(n)
+    with dfx.FlowEngine(w, h, "farn", max_batch=4) as eng:
+        host = eng.calc_optflows(frames, 1)
+        d_frames = torch.from_numpy(np.stack(frames)).cuda()
+        d_flows = torch.empty((n - 1, h, w, 2), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        eng.calc_optflows_device(d_frames.data_ptr(), w, w * h, n, 1, d_flows.data_ptr(), w * h * 2)
+        got = d_flows.cpu().numpy()
+    for i in range(n - 1):
+        assert np.array_equal(got[i], host[i])
