@@ -1,0 +1,114 @@
+// include/dense_flow.h — the reference's public API (/root/reference/include/dense_flow.h:6-100) on top
+// of the MI355X C ABI (include/dfx.h).  Same names, argument meaning and error behaviour:
+//   calcDenseFlowVideoGPU(...)      reference :6-8,  body src/denseflow_gpu.cpp:479-497
+//   class FlowBuffer                reference :10-18
+//   class DenseFlow                 reference :20-100 (launch, extract_frames_only, get_processed_total_*)
+// The only member that touches the GPU is calc_optflows_imp (reference :58-59, body
+// src/denseflow_gpu.cpp:282-370); here it calls dfx_calc_batch instead of cv::cuda::*OpticalFlow.
+#ifndef DENSEFLOW_DENSE_FLOW_H
+#define DENSEFLOW_DENSE_FLOW_H
+
+#include "common.h"
+#include "image_io.h"
+
+void calcDenseFlowVideoGPU(vector<path> video_paths, vector<path> output_dirs, string algorithm, int step, int bound,
+                           int new_width, int new_height, int new_short, bool has_class, bool use_frames,
+                           string save_type, bool is_record, bool verbose);
+
+// Extension: the same job sharded over several GPUs of one node (videos round-robin, one DenseFlow and
+// one handle per device, no collective).  devices = {0} is calcDenseFlowVideoGPU.
+void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_dirs, string algorithm, int step,
+                                int bound, int new_width, int new_height, int new_short, bool has_class,
+                                bool use_frames, string save_type, bool is_record, bool verbose, vector<int> devices);
+
+class FlowBuffer {
+  public:
+    vector<Mat> item_data;
+    path output_dir;
+    int base_start;
+    bool last_buffer;
+    FlowBuffer(vector<Mat> item_data, path output_dir, int base_start, bool last_buffer)
+        : item_data(std::move(item_data)), output_dir(std::move(output_dir)), base_start(base_start),
+          last_buffer(last_buffer) {}
+};
+
+// Bounded producer/consumer queue (the reference hand-rolls two of these with a mutex and two
+// condition variables each, include/dense_flow.h:35-47).
+class FlowBufferQueue {
+  public:
+    explicit FlowBufferQueue(size_t maxsize) : maxsize_(maxsize) {}
+    void push(FlowBuffer b, bool is_final);
+    // pops one buffer; *was_final tells the consumer that no further buffer will ever arrive
+    FlowBuffer pop(bool *was_final);
+    // a stage died: producers stop blocking, consumers see an empty final buffer
+    void close();
+
+  private:
+    size_t maxsize_;
+    mutex mtx_;
+    condition_variable not_full_, not_empty_;
+    queue<std::pair<FlowBuffer, bool>> q_;
+    bool closed_ = false;
+};
+
+class DenseFlow {
+  private:
+    vector<path> video_paths;
+    vector<path> output_dirs;
+    string algorithm;
+    string save_type;
+    int step;
+    int bound;
+    int new_width;
+    int new_height;
+    int new_short;
+    bool has_class;
+    bool is_record;
+    int device;
+
+    int batch_maxsize;
+    FlowBufferQueue frames_gray_queue;
+    FlowBufferQueue flows_queue;
+    unsigned long total_frames;
+    unsigned long total_flows;
+
+    // the device engine (replaces Ptr<cuda::*OpticalFlow> + cv::cuda::Stream)
+    dfx_handle dfx_;
+    Size dfx_size_;
+
+    bool check_param();
+    bool get_new_size(const VideoCapture &video_stream, const vector<path> &frames_path, bool use_frames,
+                      Size &new_size, int &frames_num);
+    bool load_frames_batch(VideoCapture &video_stream, const vector<path> &frames_path, bool use_frames,
+                           vector<Mat> &frames_gray, bool do_resize, const Size &size, bool to_gray);
+    int load_frames_video(VideoCapture &video_stream, vector<path> &frames_path, bool use_frames, bool do_resize,
+                          const Size &size, path output_dir, bool is_last, bool verbose);
+    void calc_optflows_imp(const FlowBuffer &frames_gray, const string &algorithm, int step, bool verbose,
+                           bool is_final);
+    void load_frames(bool use_frames, string save_type, bool verbose = true);
+    void calc_optflows(bool verbose = true);
+    void encode_save(string save_type, bool verbose = true);
+    int extract_frames_video(VideoCapture &video_stream, vector<path> &frames_path, bool use_frames, bool do_resize,
+                             const Size &size, path output_dir, bool verbose);
+    friend struct DenseFlowTestAccess;
+
+  public:
+    void launch(bool use_frames, string save_type, bool verbose);
+    void extract_frames_only(bool use_frames, bool verbose);
+    unsigned long get_processed_total_frames() { return total_frames; }
+    unsigned long get_processed_total_flows() { return total_flows; }
+
+    DenseFlow(vector<path> video_paths, vector<path> output_dirs, string algorithm, int step, int bound, int new_width,
+              int new_height, int new_short, bool has_class, bool is_record, string save_type, int device = 0);
+    ~DenseFlow();
+    DenseFlow(const DenseFlow &) = delete;
+    DenseFlow &operator=(const DenseFlow &) = delete;
+};
+
+// Test hook: drive the GPU operator on in-memory frames exactly as calc_optflows does.
+struct DenseFlowTestAccess {
+    static vector<Mat> run_calc_optflows_imp(DenseFlow &d, const vector<Mat> &frames_gray, const string &algorithm,
+                                             int step);
+};
+
+#endif // DENSEFLOW_DENSE_FLOW_H

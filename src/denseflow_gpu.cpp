@@ -1,0 +1,480 @@
+// src/denseflow_gpu.cpp — the host shell: denseflow's three-stage pipeline (load -> flow -> encode/save)
+// with the flow stage running on MI355X through the C ABI (include/dfx.h).
+//
+// Mirrors /root/reference/src/denseflow_gpu.cpp: check_param :9-42 (same messages), get_new_size :44-80,
+// extract_frames_only :82-144, load_frames_batch/video :146-217, load_frames :219-280,
+// calc_optflows_imp :282-370 (the hot path; here one dfx_calc_batch per FlowBuffer),
+// calc_optflows :372-394, encode_save :396-477, calcDenseFlowVideoGPU :479-497 (same summary line).
+// Re-designed rather than transcribed: bounded queues are a small class, the "ready_to_exit" flags
+// travel with the buffers (no unsynchronised bools), media I/O is decoder-free (image_io.h).
+#include "dense_flow.h"
+
+#include <algorithm>
+#include <cmath>
+
+#include "utils.h"
+
+// ------------------------------------------------------------------------------------------------ queue
+
+void FlowBufferQueue::push(FlowBuffer b, bool is_final) {
+    unique_lock<mutex> lock(mtx_);
+    not_full_.wait(lock, [&] { return closed_ || q_.size() < maxsize_; });
+    if (closed_)
+        return;
+    q_.emplace(std::move(b), is_final);
+    not_empty_.notify_all();
+}
+
+void FlowBufferQueue::close() {
+    unique_lock<mutex> lock(mtx_);
+    closed_ = true;
+    not_full_.notify_all();
+    not_empty_.notify_all();
+}
+
+FlowBuffer FlowBufferQueue::pop(bool *was_final) {
+    unique_lock<mutex> lock(mtx_);
+    not_empty_.wait(lock, [&] { return closed_ || !q_.empty(); });
+    if (q_.empty()) { // closed
+        *was_final = true;
+        return FlowBuffer({}, path(), 0, false);
+    }
+    std::pair<FlowBuffer, bool> item = std::move(q_.front());
+    q_.pop();
+    not_full_.notify_all();
+    *was_final = item.second;
+    return std::move(item.first);
+}
+
+// ------------------------------------------------------------------------------------------------ ctor / params
+
+DenseFlow::DenseFlow(vector<path> video_paths, vector<path> output_dirs, string algorithm, int step, int bound,
+                     int new_width, int new_height, int new_short, bool has_class, bool is_record, string save_type,
+                     int device)
+    : video_paths(std::move(video_paths)), output_dirs(std::move(output_dirs)), algorithm(std::move(algorithm)),
+      save_type(std::move(save_type)), step(step), bound(bound), new_width(new_width), new_height(new_height),
+      new_short(new_short), has_class(has_class), is_record(is_record), device(device), batch_maxsize(512),
+      frames_gray_queue(3), flows_queue(3), total_frames(0), total_flows(0), dfx_(nullptr) {
+    if (!check_param())
+        throw std::runtime_error("check init param error.");
+}
+
+DenseFlow::~DenseFlow() {
+    if (dfx_)
+        dfx_destroy(dfx_);
+}
+
+bool DenseFlow::check_param() {
+    for (size_t i = 0; i < video_paths.size(); i++) {
+        if (!exists(video_paths[i])) {
+            cout << video_paths[i] << " does not exist!" << endl;
+            return false;
+        }
+        if (!is_directory(output_dirs[i])) {
+            cout << output_dirs[i] << " is not a valid dir!" << endl;
+            return false;
+        }
+    }
+    if (algorithm != "nv" && algorithm != "tvl1" && algorithm != "farn" && algorithm != "brox") {
+        cout << algorithm << " not supported!" << endl;
+        return false;
+    }
+    if (bound <= 0) {
+        cout << "bound should > 0!" << endl;
+        return false;
+    }
+    if (new_height < 0 || new_width < 0 || new_short < 0) {
+        cout << "height and width cannot < 0!" << endl;
+        return false;
+    }
+    if (new_short > 0 && new_height + new_width != 0) {
+        cout << "do not set height and width when set short!" << endl;
+        return false;
+    }
+    if (save_type != "jpg" && save_type != "png" && save_type != "h5") {
+        cout << "only jpg/png/h5 are supported (no " << save_type << ") for output" << endl;
+        return false;
+    }
+    return true;
+}
+
+bool DenseFlow::get_new_size(const VideoCapture &video_stream, const vector<path> &frames_path, bool use_frames,
+                             Size &new_size, int &frames_num) {
+    int width, height;
+    if (use_frames) {
+        Mat src;
+        if (!imreadGray(frames_path[0].string(), src))
+            throw std::runtime_error("cannot read frame " + frames_path[0].string());
+        width = src.cols;
+        height = src.rows;
+        frames_num = (int)frames_path.size();
+    } else {
+        width = video_stream.width();
+        height = video_stream.height();
+        frames_num = video_stream.frameCount();
+    }
+    bool do_resize = true;
+    if (new_width > 0 && new_height > 0) {
+        new_size = Size(new_width, new_height);
+    } else if (new_width > 0) {
+        new_size = Size(new_width, (int)std::round(height * 1.0 / width * new_width));
+    } else if (new_height > 0) {
+        new_size = Size((int)std::round(width * 1.0 / height * new_height), new_height);
+    } else if (new_short > 0 && std::min(width, height) > new_short) {
+        if (width < height)
+            new_size = Size(new_short, (int)std::round(height * 1.0 / width * new_short));
+        else
+            new_size = Size((int)std::round(width * 1.0 / height * new_short), new_short);
+    } else {
+        do_resize = false;
+    }
+    return do_resize;
+}
+
+// ------------------------------------------------------------------------------------------------ loading
+
+static vector<path> list_frames(const path &dir) {
+    vector<path> out;
+    for (directory_iterator it(dir), end; it != end; ++it) {
+        const string ext = it->path().extension().string();
+        if (!is_regular_file(it->status()) || (ext != ".pgm" && ext != ".ppm"))
+            continue; // the reference takes .jpg here (:249); this build has no JPEG decoder
+        out.push_back(it->path());
+    }
+    std::sort(out.begin(), out.end());
+    return out;
+}
+
+bool DenseFlow::load_frames_batch(VideoCapture &video_stream, const vector<path> &frames_path, bool use_frames,
+                                  vector<Mat> &frames_gray, bool do_resize, const Size &size, bool to_gray) {
+    (void)to_gray; // sources are gray already (Y plane / PGM / BGR2GRAY in imreadGray)
+    int cnt = 0;
+    while (cnt < batch_maxsize) {
+        Mat frame;
+        if (use_frames) {
+            if (cnt == (int)frames_path.size())
+                return false;
+            if (!imreadGray(frames_path[cnt].string(), frame))
+                throw std::runtime_error("cannot read frame " + frames_path[cnt].string());
+        } else if (!video_stream.read(frame)) {
+            return false;
+        }
+        if (do_resize) {
+            Mat resized;
+            resizeLinear(frame, resized, size);
+            frames_gray.push_back(resized);
+        } else {
+            frames_gray.push_back(frame);
+        }
+        cnt++;
+    }
+    return true;
+}
+
+int DenseFlow::load_frames_video(VideoCapture &video_stream, vector<path> &frames_path, bool use_frames,
+                                 bool do_resize, const Size &size, path output_dir, bool is_last, bool verbose) {
+    int video_flow_idx = 0;
+    const int astep = std::abs(step);
+    vector<Mat> padding;
+    while (true) {
+        vector<Mat> frames_gray;
+        const bool is_open = load_frames_batch(video_stream, frames_path, use_frames, frames_gray, do_resize, size, true);
+        vector<Mat> padded(padding);
+        padded.insert(padded.end(), frames_gray.begin(), frames_gray.end());
+        if (verbose)
+            cout << "push frames gray, video_flow_idx " << video_flow_idx << ", batch_size " << frames_gray.size()
+                 << endl;
+        frames_gray_queue.push(FlowBuffer(padded, output_dir, video_flow_idx, !is_open), is_last && !is_open);
+        // the last |step| frames are needed again as the head of the next buffer (:204-207)
+        padding.assign(padded.end() - std::min<size_t>(astep, padded.size()), padded.end());
+        const int M = (int)padded.size() - astep;
+        video_flow_idx += M;
+        if (!is_open)
+            break;
+        if (use_frames)
+            frames_path.erase(frames_path.begin(), frames_path.begin() + std::min<size_t>(M, frames_path.size()));
+    }
+    return video_flow_idx + astep;
+}
+
+void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
+    bool final_pushed = false;
+    for (size_t i = 0; i < video_paths.size(); i++) {
+        const path video_path = video_paths[i];
+        const path output_dir = output_dirs[i];
+        if (save_type == "h5") // this build has no HDF5, like the reference compiled with USE_HDF5=OFF (:238)
+            throw std::runtime_error("HDF5 support is not enabled, pls recompile");
+        VideoCapture video_stream;
+        vector<path> frames_path;
+        if (use_frames) {
+            frames_path = list_frames(video_path);
+            if (frames_path.empty()) {
+                if (verbose)
+                    cout << video_path << " is empty!" << endl;
+                continue;
+            }
+        } else if (!video_stream.open(video_path.string())) {
+            throw std::runtime_error("cannot open video_path stream:" + video_path.string());
+        }
+        Size size;
+        int frames_num;
+        const bool do_resize = get_new_size(video_stream, frames_path, use_frames, size, frames_num);
+        if (verbose)
+            cout << video_path << ", frames ≈ " << frames_num << endl;
+        const bool is_last = i == video_paths.size() - 1;
+        frames_num = load_frames_video(video_stream, frames_path, use_frames, do_resize, size, output_dir, is_last,
+                                       verbose);
+        final_pushed = is_last;
+        total_frames += frames_num;
+        if (verbose)
+            cout << "loaded video " << video_path << ", " << frames_num << " frames" << endl;
+    }
+    if (!final_pushed) // e.g. the last input was empty: still let the downstream stages finish
+        frames_gray_queue.push(FlowBuffer({}, path(), 0, false), true);
+    if (verbose)
+        cout << "load frames exit." << endl;
+}
+
+// ------------------------------------------------------------------------------------------------ the hot path
+
+// One FlowBuffer of gray frames -> M = max(N - |step|, 0) flows, on the GPU.
+void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &algorithm, int step, bool verbose,
+                                  bool is_final) {
+    const int N = (int)frames_gray.item_data.size();
+    const int M = std::max(N - std::abs(step), 0);
+    vector<Mat> flows(M);
+    if (M > 0) {
+        dfx_algo algo;
+        const int rc = dfx_algo_from_name(algorithm.c_str(), &algo);
+        if (rc != DFX_OK) { // "NV hardware flow not enabled, pls recompile" / "unknown optical algorithm <a>"
+            char msg[256];
+            throw std::runtime_error(dfx_algo_error_message(rc, algorithm.c_str(), msg, sizeof msg));
+        }
+        const Size sz = frames_gray.item_data[0].size();
+        if (!dfx_ || !(sz == dfx_size_)) { // sized per video; reused across its FlowBuffers
+            if (dfx_)
+                dfx_destroy(dfx_);
+            dfx_ = nullptr;
+            if (dfx_create(&dfx_, device, algo, sz.width, sz.height, nullptr) != DFX_OK)
+                throw std::runtime_error(dfx_last_error(nullptr));
+            dfx_size_ = sz;
+        }
+        vector<const uint8_t *> in(N);
+        vector<float *> out(M);
+        for (int i = 0; i < N; ++i)
+            in[i] = frames_gray.item_data[i].ptr<uint8_t>();
+        for (int i = 0; i < M; ++i) {
+            flows[i].create(sz, CV_32FC2);
+            out[i] = flows[i].ptr<float>();
+        }
+        if (dfx_calc_batch(dfx_, in.data(), frames_gray.item_data[0].step, N, step, out.data(), flows[0].step) != DFX_OK)
+            throw std::runtime_error(dfx_last_error(dfx_));
+        total_flows += M;
+    }
+    if (verbose)
+        cout << "flows queue push a item" << endl;
+    flows_queue.push(FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start, frames_gray.last_buffer),
+                     is_final);
+}
+
+void DenseFlow::calc_optflows(bool verbose) {
+    while (true) {
+        bool is_final = false;
+        FlowBuffer frames_gray = frames_gray_queue.pop(&is_final);
+        calc_optflows_imp(frames_gray, algorithm, step, false, is_final);
+        if (is_final)
+            break;
+    }
+    if (verbose)
+        cout << "calc optflows exit." << endl;
+}
+
+// ------------------------------------------------------------------------------------------------ encode + save
+
+void DenseFlow::encode_save(string save_type, bool verbose) {
+    while (true) {
+        bool is_final = false;
+        FlowBuffer flow_buffer = flows_queue.pop(&is_final);
+        const int M = (int)flow_buffer.item_data.size();
+        if (save_type == "jpg") {
+            vector<vector<uchar>> output_x, output_y;
+            for (int i = 0; i < M; ++i) {
+                Mat planes[2];
+                split(flow_buffer.item_data[i], planes);
+                vector<uchar> str_x, str_y;
+                encodeFlowMap(planes[0], planes[1], str_x, str_y, bound);
+                output_x.push_back(std::move(str_x));
+                output_y.push_back(std::move(str_y));
+            }
+            writeFlowImages(output_x, (flow_buffer.output_dir / "flow_x").string(), step, flow_buffer.base_start);
+            writeFlowImages(output_y, (flow_buffer.output_dir / "flow_y").string(), step, flow_buffer.base_start);
+        } else if (save_type == "png") {
+            vector<vector<uchar>> output;
+            for (int i = 0; i < M; ++i) {
+                Mat planes[2];
+                split(flow_buffer.item_data[i], planes);
+                vector<uchar> str;
+                encodeFlowMapPng(planes[0], planes[1], str);
+                output.push_back(std::move(str));
+            }
+            writeFlowImagesPng(output, (flow_buffer.output_dir / "flow").string(), step, flow_buffer.base_start);
+        }
+        // mark the video done after its last buffer has been written (resume support, :456-470)
+        if (is_record && flow_buffer.last_buffer) {
+            path donedir, title;
+            if (has_class) {
+                donedir = flow_buffer.output_dir.parent_path().parent_path() / ".done" /
+                          flow_buffer.output_dir.parent_path().filename();
+                title = flow_buffer.output_dir.parent_path().filename() / flow_buffer.output_dir.filename();
+            } else {
+                donedir = flow_buffer.output_dir.parent_path() / ".done";
+                title = flow_buffer.output_dir.filename();
+            }
+            createFile(donedir / flow_buffer.output_dir.stem().string());
+            cout << "done video " << title << endl;
+        }
+        if (is_final)
+            break;
+    }
+    if (verbose)
+        cout << "post process exit." << endl;
+}
+
+// ------------------------------------------------------------------------------------------------ frames only (-s=0)
+
+int DenseFlow::extract_frames_video(VideoCapture &video_stream, vector<path> &frames_path, bool use_frames,
+                                    bool do_resize, const Size &size, path output_dir, bool verbose) {
+    (void)verbose;
+    int video_frame_idx = 0;
+    while (true) {
+        vector<Mat> frames;
+        const bool is_open = load_frames_batch(video_stream, frames_path, use_frames, frames, do_resize, size, false);
+        vector<vector<uchar>> output_img;
+        for (const Mat &f : frames) {
+            vector<uchar> str_img;
+            imencodeJpeg(f, str_img);
+            output_img.push_back(std::move(str_img));
+        }
+        writeImages(output_img, (output_dir / "img").string(), video_frame_idx);
+        video_frame_idx += (int)frames.size();
+        if (!is_open)
+            break;
+        if (use_frames)
+            frames_path.erase(frames_path.begin(), frames_path.begin() + frames.size());
+    }
+    return video_frame_idx;
+}
+
+void DenseFlow::extract_frames_only(bool use_frames, bool verbose) {
+    for (size_t i = 0; i < video_paths.size(); i++) {
+        VideoCapture video_stream;
+        vector<path> frames_path;
+        if (use_frames) {
+            frames_path = list_frames(video_paths[i]);
+            if (frames_path.empty()) {
+                if (verbose)
+                    cout << video_paths[i] << " is empty!" << endl;
+                continue;
+            }
+        } else if (!video_stream.open(video_paths[i].string())) {
+            throw std::runtime_error("cannot open video_path stream:" + video_paths[i].string());
+        }
+        Size size;
+        int frames_num;
+        const bool do_resize = get_new_size(video_stream, frames_path, use_frames, size, frames_num);
+        frames_num = extract_frames_video(video_stream, frames_path, use_frames, do_resize, size, output_dirs[i], verbose);
+        total_frames += frames_num;
+        if (verbose)
+            cout << "extracted frames of video " << video_paths[i] << ", " << frames_num << " frames" << endl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ entry points
+
+void DenseFlow::launch(bool use_frames, string save_type, bool verbose) {
+    std::exception_ptr err[3];
+    auto guarded = [&](int k, auto fn) {
+        return [&, k, fn] {
+            try {
+                fn();
+            } catch (...) { // the reference lets worker exceptions hit std::terminate; report them instead
+                err[k] = std::current_exception();
+                frames_gray_queue.close(); // unblock the other stages; they wind down on an empty final buffer
+                flows_queue.close();
+            }
+        };
+    };
+    thread t_load(guarded(0, [&] { load_frames(use_frames, save_type, verbose); }));
+    thread t_calc(guarded(1, [&] { calc_optflows(false); }));
+    thread t_save(guarded(2, [&] { encode_save(save_type, false); }));
+    t_load.join();
+    t_calc.join();
+    t_save.join();
+    for (auto &e : err)
+        if (e)
+            std::rethrow_exception(e);
+}
+
+vector<Mat> DenseFlowTestAccess::run_calc_optflows_imp(DenseFlow &d, const vector<Mat> &frames_gray,
+                                                        const string &algorithm, int step) {
+    d.calc_optflows_imp(FlowBuffer(frames_gray, path(), 0, true), algorithm, step, false, true);
+    bool fin = false;
+    return d.flows_queue.pop(&fin).item_data;
+}
+
+static void print_summary(size_t n_videos, unsigned long N, unsigned long F, const string &algorithm, double secs) {
+    cout << n_videos << " videos (" << N << " frames, " << F << " " << algorithm << " flows) processed, using " << secs
+         << "s, decoding speed " << N / secs << "fps, flow speed " << F / secs << "fps" << endl;
+}
+
+void calcDenseFlowVideoGPU(vector<path> video_paths, vector<path> output_dirs, string algorithm, int step, int bound,
+                           int new_width, int new_height, int new_short, bool has_class, bool use_frames,
+                           string save_type, bool is_record, bool verbose) {
+    calcDenseFlowVideoMultiGPU(video_paths, output_dirs, algorithm, step, bound, new_width, new_height, new_short,
+                               has_class, use_frames, save_type, is_record, verbose, vector<int>{0});
+}
+
+void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_dirs, string algorithm, int step,
+                                int bound, int new_width, int new_height, int new_short, bool has_class,
+                                bool use_frames, string save_type, bool is_record, bool verbose, vector<int> devices) {
+    if (devices.empty())
+        devices.push_back(0);
+    const size_t G = std::min(devices.size(), std::max<size_t>(video_paths.size(), 1));
+    // videos are dealt round-robin to the devices; each device runs its own three-thread pipeline
+    vector<std::unique_ptr<DenseFlow>> workers;
+    for (size_t g = 0; g < G; ++g) {
+        vector<path> vp, od;
+        for (size_t i = g; i < video_paths.size(); i += G) {
+            vp.push_back(video_paths[i]);
+            od.push_back(output_dirs[i]);
+        }
+        workers.emplace_back(new DenseFlow(vp, od, algorithm, step, bound, new_width, new_height, new_short, has_class,
+                                           is_record, save_type, devices[g]));
+    }
+    const double start_t = CurrentSeconds();
+    vector<std::exception_ptr> errs(G);
+    vector<thread> threads;
+    for (size_t g = 0; g < G; ++g)
+        threads.emplace_back([&, g] {
+            try {
+                if (step == 0)
+                    workers[g]->extract_frames_only(use_frames, verbose);
+                else
+                    workers[g]->launch(use_frames, save_type, verbose);
+            } catch (...) {
+                errs[g] = std::current_exception();
+            }
+        });
+    for (auto &t : threads)
+        t.join();
+    for (auto &e : errs)
+        if (e)
+            std::rethrow_exception(e);
+    const double end_t = CurrentSeconds();
+    unsigned long N = 0, F = 0;
+    for (auto &w : workers) {
+        N += w->get_processed_total_frames();
+        F += w->get_processed_total_flows();
+    }
+    print_summary(video_paths.size(), N, F, algorithm, std::max(end_t - start_t, 1e-3));
+}

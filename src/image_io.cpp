@@ -1,0 +1,389 @@
+// src/image_io.cpp — decoder-free media I/O for the host shell: Y4M / PGM / PPM readers, bilinear
+// resize, a baseline JPEG encoder (ITU-T T.81 Annex K tables) and a PNG writer (stored deflate).
+// Host glue outside the hot path; nothing here runs on the GPU.
+#include "image_io.h"
+
+#include <algorithm>
+#include <cmath>
+
+// ------------------------------------------------------------------------------------------------
+// YUV4MPEG2
+
+bool VideoCapture::open(const string &file) {
+    FILE *fp = fopen(file.c_str(), "rb");
+    if (!fp)
+        return false;
+    f_.reset(fp, fclose);
+    char line[512];
+    if (!fgets(line, sizeof line, fp) || strncmp(line, "YUV4MPEG2", 9) != 0) {
+        f_.reset();
+        return false;
+    }
+    string cs = "420";
+    for (char *tok = strtok(line + 9, " \n"); tok; tok = strtok(nullptr, " \n")) {
+        if (tok[0] == 'W')
+            w_ = atoi(tok + 1);
+        else if (tok[0] == 'H')
+            h_ = atoi(tok + 1);
+        else if (tok[0] == 'C')
+            cs = tok + 1;
+    }
+    if (w_ <= 0 || h_ <= 0) {
+        f_.reset();
+        return false;
+    }
+    const size_t cw = (w_ + 1) / 2, ch = (h_ + 1) / 2;
+    if (cs.rfind("mono", 0) == 0)
+        chroma_bytes_ = 0;
+    else if (cs.rfind("444", 0) == 0)
+        chroma_bytes_ = 2 * (size_t)w_ * h_;
+    else if (cs.rfind("422", 0) == 0)
+        chroma_bytes_ = 2 * cw * h_;
+    else
+        chroma_bytes_ = 2 * cw * ch; // 420*
+    // frame count from the file size (every frame is "FRAME\n" + planes when no frame parameters are used)
+    const long here = ftell(fp);
+    fseek(fp, 0, SEEK_END);
+    const long end = ftell(fp);
+    fseek(fp, here, SEEK_SET);
+    const size_t per = 6 + (size_t)w_ * h_ + chroma_bytes_;
+    frames_ = (int)((end - here) / (long)per);
+    return true;
+}
+
+bool VideoCapture::read(Mat &gray) {
+    if (!f_)
+        return false;
+    FILE *fp = f_.get();
+    char line[256];
+    if (!fgets(line, sizeof line, fp) || strncmp(line, "FRAME", 5) != 0)
+        return false;
+    gray.create(Size(w_, h_), CV_8UC1);
+    if (fread(gray.data(), 1, (size_t)w_ * h_, fp) != (size_t)w_ * h_)
+        return false;
+    if (chroma_bytes_)
+        fseek(fp, (long)chroma_bytes_, SEEK_CUR);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PGM / PPM
+
+static bool pnm_token(FILE *fp, int &v) {
+    int c = fgetc(fp);
+    for (;;) {
+        while (c == ' ' || c == '\n' || c == '\r' || c == '\t')
+            c = fgetc(fp);
+        if (c == '#') {
+            while (c != '\n' && c != EOF)
+                c = fgetc(fp);
+            continue;
+        }
+        break;
+    }
+    if (c < '0' || c > '9')
+        return false;
+    v = 0;
+    while (c >= '0' && c <= '9') {
+        v = v * 10 + (c - '0');
+        c = fgetc(fp);
+    }
+    return true; // exactly one whitespace byte after the token has been consumed
+}
+
+bool imreadGray(const string &file, Mat &gray) {
+    FILE *fp = fopen(file.c_str(), "rb");
+    if (!fp)
+        return false;
+    std::shared_ptr<FILE> guard(fp, fclose);
+    char magic[3] = {0, 0, 0};
+    if (fread(magic, 1, 2, fp) != 2 || magic[0] != 'P' || (magic[1] != '5' && magic[1] != '6'))
+        return false;
+    int w, h, maxv;
+    if (!pnm_token(fp, w) || !pnm_token(fp, h) || !pnm_token(fp, maxv) || maxv != 255 || w <= 0 || h <= 0)
+        return false;
+    gray.create(Size(w, h), CV_8UC1);
+    if (magic[1] == '5')
+        return fread(gray.data(), 1, (size_t)w * h, fp) == (size_t)w * h;
+    vector<uchar> rgb((size_t)w * h * 3);
+    if (fread(rgb.data(), 1, rgb.size(), fp) != rgb.size())
+        return false;
+    uchar *g = gray.data();
+    for (size_t i = 0; i < (size_t)w * h; ++i) // cvtColor BGR2GRAY fixed-point weights (R 4899, G 9617, B 1868, >> 14)
+        g[i] = (uchar)((rgb[3 * i] * 4899 + rgb[3 * i + 1] * 9617 + rgb[3 * i + 2] * 1868 + 8192) >> 14);
+    return true;
+}
+
+void resizeLinear(const Mat &src, Mat &dst, Size size) {
+    dst.create(size, CV_8UC1);
+    const double fx = (double)src.cols / size.width, fy = (double)src.rows / size.height;
+    for (int y = 0; y < size.height; ++y) {
+        double sy = (y + 0.5) * fy - 0.5;
+        int y0 = (int)std::floor(sy);
+        double wy = sy - y0;
+        int y1 = std::min(std::max(y0 + 1, 0), src.rows - 1);
+        y0 = std::min(std::max(y0, 0), src.rows - 1);
+        const uchar *r0 = src.ptr<uchar>(y0), *r1 = src.ptr<uchar>(y1);
+        uchar *d = dst.ptr<uchar>(y);
+        for (int x = 0; x < size.width; ++x) {
+            double sx = (x + 0.5) * fx - 0.5;
+            int x0 = (int)std::floor(sx);
+            double wx = sx - x0;
+            int x1 = std::min(std::max(x0 + 1, 0), src.cols - 1);
+            x0 = std::min(std::max(x0, 0), src.cols - 1);
+            const double v = (1 - wy) * ((1 - wx) * r0[x0] + wx * r0[x1]) + wy * ((1 - wx) * r1[x0] + wx * r1[x1]);
+            d[x] = (uchar)std::min(255.0, std::max(0.0, std::nearbyint(v)));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// baseline JPEG encoder, 8-bit gray (T.81): standard luminance quantisation and Huffman tables
+
+namespace {
+
+const uchar kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                           41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                           30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const uchar kLumaQ[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
+                          14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
+                          18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+                          49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uchar kDcBits[17] = {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uchar kDcVal[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uchar kAcBits[17] = {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uchar kAcVal[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
+    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
+    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
+    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+struct HuffTable {
+    unsigned short code[256];
+    uchar len[256];
+    void build(const uchar *bits, const uchar *vals) {
+        memset(len, 0, sizeof len);
+        unsigned code_v = 0;
+        int k = 0;
+        for (int l = 1; l <= 16; ++l) {
+            for (int i = 0; i < bits[l]; ++i, ++k) {
+                code[vals[k]] = (unsigned short)code_v++;
+                len[vals[k]] = (uchar)l;
+            }
+            code_v <<= 1;
+        }
+    }
+};
+
+struct BitWriter {
+    vector<uchar> &out;
+    unsigned acc = 0;
+    int nbits = 0;
+    explicit BitWriter(vector<uchar> &o) : out(o) {}
+    void put(unsigned code, int len) {
+        acc = (acc << len) | (code & ((1u << len) - 1));
+        nbits += len;
+        while (nbits >= 8) {
+            const uchar b = (uchar)(acc >> (nbits - 8));
+            out.push_back(b);
+            if (b == 0xFF)
+                out.push_back(0);
+            nbits -= 8;
+        }
+    }
+    void flush() {
+        if (nbits > 0)
+            put((1u << (8 - nbits)) - 1, 8 - nbits);
+    }
+};
+
+void put16(vector<uchar> &o, int v) {
+    o.push_back((uchar)(v >> 8));
+    o.push_back((uchar)v);
+}
+
+} // namespace
+
+bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
+    if (gray.empty() || gray.type() != CV_8UC1)
+        return false;
+    quality = std::min(100, std::max(1, quality));
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    uchar q[64];
+    for (int i = 0; i < 64; ++i)
+        q[i] = (uchar)std::min(255, std::max(1, (kLumaQ[i] * scale + 50) / 100));
+    static HuffTable dc, ac;
+    static bool built = false;
+    static float cosv[8][8];
+    if (!built) {
+        dc.build(kDcBits, kDcVal);
+        ac.build(kAcBits, kAcVal);
+        for (int u = 0; u < 8; ++u)
+            for (int x = 0; x < 8; ++x)
+                cosv[u][x] = (float)(std::cos((2 * x + 1) * u * M_PI / 16.0) * (u == 0 ? std::sqrt(0.125) : 0.5));
+        built = true;
+    }
+    const int W = gray.cols, H = gray.rows;
+    out.clear();
+    out.reserve((size_t)W * H / 4 + 1024);
+    const uchar soi_app0[] = {0xFF, 0xD8, 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+    out.insert(out.end(), soi_app0, soi_app0 + sizeof soi_app0);
+    out.push_back(0xFF), out.push_back(0xDB), put16(out, 67), out.push_back(0);
+    for (int i = 0; i < 64; ++i)
+        out.push_back(q[kZigzag[i]]);
+    out.push_back(0xFF), out.push_back(0xC0), put16(out, 11), out.push_back(8), put16(out, H), put16(out, W);
+    out.push_back(1), out.push_back(1), out.push_back(0x11), out.push_back(0);
+    out.push_back(0xFF), out.push_back(0xC4), put16(out, 2 + 1 + 16 + 12), out.push_back(0x00);
+    out.insert(out.end(), kDcBits + 1, kDcBits + 17), out.insert(out.end(), kDcVal, kDcVal + 12);
+    out.push_back(0xFF), out.push_back(0xC4), put16(out, 2 + 1 + 16 + 162), out.push_back(0x10);
+    out.insert(out.end(), kAcBits + 1, kAcBits + 17), out.insert(out.end(), kAcVal, kAcVal + 162);
+    const uchar sos[] = {0xFF, 0xDA, 0, 8, 1, 1, 0x00, 0, 63, 0};
+    out.insert(out.end(), sos, sos + sizeof sos);
+
+    BitWriter bw(out);
+    int prev_dc = 0;
+    for (int by = 0; by < H; by += 8) {
+        for (int bx = 0; bx < W; bx += 8) {
+            float blk[8][8], tmp[8][8];
+            for (int y = 0; y < 8; ++y) {
+                const uchar *row = gray.ptr<uchar>(std::min(by + y, H - 1));
+                for (int x = 0; x < 8; ++x)
+                    blk[y][x] = (float)row[std::min(bx + x, W - 1)] - 128.f;
+            }
+            for (int y = 0; y < 8; ++y)
+                for (int u = 0; u < 8; ++u) {
+                    float s = 0;
+                    for (int x = 0; x < 8; ++x)
+                        s += blk[y][x] * cosv[u][x];
+                    tmp[y][u] = s;
+                }
+            int coef[64];
+            for (int v = 0; v < 8; ++v)
+                for (int u = 0; u < 8; ++u) {
+                    float s = 0;
+                    for (int y = 0; y < 8; ++y)
+                        s += tmp[y][u] * cosv[v][y];
+                    coef[v * 8 + u] = (int)std::lrintf(s / q[v * 8 + u]);
+                }
+            // DC
+            int diff = coef[0] - prev_dc;
+            prev_dc = coef[0];
+            int a = diff < 0 ? -diff : diff, nb = 0;
+            while (a) {
+                ++nb;
+                a >>= 1;
+            }
+            bw.put(dc.code[nb], dc.len[nb]);
+            if (nb)
+                bw.put((unsigned)(diff < 0 ? diff - 1 : diff), nb);
+            // AC
+            int run = 0;
+            for (int k = 1; k < 64; ++k) {
+                const int v = coef[kZigzag[k]];
+                if (v == 0) {
+                    ++run;
+                    continue;
+                }
+                while (run > 15) {
+                    bw.put(ac.code[0xF0], ac.len[0xF0]);
+                    run -= 16;
+                }
+                int av = v < 0 ? -v : v, n = 0;
+                while (av) {
+                    ++n;
+                    av >>= 1;
+                }
+                const int sym = (run << 4) | n;
+                bw.put(ac.code[sym], ac.len[sym]);
+                bw.put((unsigned)(v < 0 ? v - 1 : v), n);
+                run = 0;
+            }
+            if (run)
+                bw.put(ac.code[0x00], ac.len[0x00]);
+        }
+    }
+    bw.flush();
+    out.push_back(0xFF), out.push_back(0xD9);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PNG writer: 8-bit gray or BGR (stored as RGB), zlib "stored" blocks
+
+namespace {
+unsigned crc_table[256];
+bool crc_ready = false;
+unsigned crc32_of(const uchar *p, size_t n, unsigned crc = 0xFFFFFFFFu) {
+    if (!crc_ready) {
+        for (unsigned i = 0; i < 256; ++i) {
+            unsigned c = i;
+            for (int k = 0; k < 8; ++k)
+                c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[i] = c;
+        }
+        crc_ready = true;
+    }
+    for (size_t i = 0; i < n; ++i)
+        crc = crc_table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return crc;
+}
+void put32(vector<uchar> &o, unsigned v) {
+    o.push_back((uchar)(v >> 24)), o.push_back((uchar)(v >> 16)), o.push_back((uchar)(v >> 8)), o.push_back((uchar)v);
+}
+void chunk(vector<uchar> &o, const char *type, const vector<uchar> &data) {
+    put32(o, (unsigned)data.size());
+    const size_t start = o.size();
+    o.insert(o.end(), type, type + 4);
+    o.insert(o.end(), data.begin(), data.end());
+    put32(o, crc32_of(o.data() + start, o.size() - start) ^ 0xFFFFFFFFu);
+}
+} // namespace
+
+bool imencodePng(const Mat &img, vector<uchar> &out) {
+    if (img.empty() || (img.type() != CV_8UC1 && img.type() != CV_8UC3))
+        return false;
+    const int ch = img.channels(), W = img.cols, H = img.rows;
+    vector<uchar> raw;
+    raw.reserve((size_t)H * (W * ch + 1));
+    for (int y = 0; y < H; ++y) {
+        raw.push_back(0); // filter: none
+        const uchar *r = img.ptr<uchar>(y);
+        if (ch == 1)
+            raw.insert(raw.end(), r, r + W);
+        else
+            for (int x = 0; x < W; ++x) {
+                raw.push_back(r[3 * x + 2]), raw.push_back(r[3 * x + 1]), raw.push_back(r[3 * x]);
+            }
+    }
+    vector<uchar> z;
+    z.push_back(0x78), z.push_back(0x01);
+    unsigned a = 1, b = 0;
+    for (size_t pos = 0; pos < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uchar)(n & 0xFF)), z.push_back((uchar)(n >> 8));
+        z.push_back((uchar)(~n & 0xFF)), z.push_back((uchar)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = pos; i < pos + n; ++i) {
+            a = (a + raw[i]) % 65521;
+            b = (b + a) % 65521;
+        }
+        pos += n;
+    }
+    put32(z, (b << 16) | a);
+    out.clear();
+    const uchar sig[] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    out.insert(out.end(), sig, sig + 8);
+    vector<uchar> ihdr;
+    put32(ihdr, (unsigned)W), put32(ihdr, (unsigned)H);
+    ihdr.push_back(8), ihdr.push_back(ch == 1 ? 0 : 2), ihdr.push_back(0), ihdr.push_back(0), ihdr.push_back(0);
+    chunk(out, "IHDR", ihdr);
+    chunk(out, "IDAT", z);
+    chunk(out, "IEND", vector<uchar>());
+    return true;
+}

@@ -1,0 +1,60 @@
+// tests/host_harness.cpp — TEST INFRASTRUCTURE: C wrappers around the host shell's codecs/quantisation and
+// the DenseFlow operator (calc_optflows_imp) so pytest can drive them through ctypes.
+#include <cstring>
+
+#include "../include/dense_flow.h"
+
+extern "C" {
+
+int hh_encode_jpeg(const uchar *gray, int w, int h, int quality, uchar *out, int out_cap) {
+    Mat m(Size(w, h), CV_8UC1);
+    memcpy(m.data(), gray, (size_t)w * h);
+    vector<uchar> buf;
+    if (!imencodeJpeg(m, buf, quality) || (int)buf.size() > out_cap)
+        return -1;
+    memcpy(out, buf.data(), buf.size());
+    return (int)buf.size();
+}
+
+int hh_encode_flow_png(const float *fx, const float *fy, int w, int h, uchar *out, int out_cap) {
+    Mat a(Size(w, h), CV_32FC1), b(Size(w, h), CV_32FC1);
+    memcpy(a.data(), fx, sizeof(float) * w * h);
+    memcpy(b.data(), fy, sizeof(float) * w * h);
+    vector<uchar> buf;
+    encodeFlowMapPng(a, b, buf);
+    if ((int)buf.size() > out_cap)
+        return -1;
+    memcpy(out, buf.data(), buf.size());
+    return (int)buf.size();
+}
+
+void hh_quantise(const float *fx, const float *fy, int w, int h, int bound, uchar *ox, uchar *oy) {
+    Mat a(Size(w, h), CV_32FC1), b(Size(w, h), CV_32FC1), ia(Size(w, h), CV_8UC1), ib(Size(w, h), CV_8UC1);
+    memcpy(a.data(), fx, sizeof(float) * w * h);
+    memcpy(b.data(), fy, sizeof(float) * w * h);
+    convertFlowToImage(a, b, ia, ib, -bound, bound);
+    memcpy(ox, ia.data(), (size_t)w * h);
+    memcpy(oy, ib.data(), (size_t)w * h);
+}
+
+// DenseFlow::calc_optflows_imp on n in-memory frames; flows: (n-|step|) x h x w x 2 floats. Returns #flows or <0.
+int hh_calc_optflows_imp(const uchar *frames, int n, int w, int h, const char *algorithm, int step, float *flows,
+                         char *err, int err_cap) {
+    try {
+        vector<path> none;
+        DenseFlow d(none, none, "tvl1", step, 20, 0, 0, 0, false, false, "jpg");
+        vector<Mat> fr(n);
+        for (int i = 0; i < n; ++i) {
+            fr[i].create(Size(w, h), CV_8UC1);
+            memcpy(fr[i].data(), frames + (size_t)i * w * h, (size_t)w * h);
+        }
+        vector<Mat> out = DenseFlowTestAccess::run_calc_optflows_imp(d, fr, algorithm, step);
+        for (size_t i = 0; i < out.size(); ++i)
+            memcpy(flows + i * (size_t)w * h * 2, out[i].data(), sizeof(float) * w * h * 2);
+        return (int)out.size();
+    } catch (const std::exception &e) {
+        snprintf(err, err_cap, "%s", e.what());
+        return -1;
+    }
+}
+}

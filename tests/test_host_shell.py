@@ -1,0 +1,213 @@
+"""Host shell (C++): the reference's CLI / dense_flow.h surface on the MI355X build.  CPU tests cover the
+command line (help text golden from the reference README, exit codes, error texts), quantisation, the
+decoder-free codecs and frame extraction; gpu tests run the operator and the whole CLI on the device."""
+import ctypes as C
+import io
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from denseflow_amd.synth import SynthClip
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "build", "denseflow")
+
+HELP_GOLDEN = """GPU optical flow extraction.
+Usage: denseflow [params] input
+
+\t-a, --algorithm (value:tvl1)
+\t\toptical flow algorithm (nv/tvl1/farn/brox)
+\t-b, --bound (value:32)
+\t\tmaximum of optical flow
+\t--cf, --classFolder
+\t\toutputDir/class/video/flow.jpg
+\t-f, --force
+\t\tregardless of the marked .done file
+\t-g, --gpus (value:1)
+\t\tnumber of GPUs to shard the input list over
+\t-h, --help (value:true)
+\t\tprint help message
+\t--if, --inputFrames
+\t\tinputs are frames
+\t--newHeight, --nh (value:0)
+\t\tnew height
+\t--newShort, --ns (value:0)
+\t\tshort side length
+\t--newWidth, --nw (value:0)
+\t\tnew width
+\t-o, --outputDir (value:.)
+\t\troot dir of output
+\t-s, --step (value:0)
+\t\tright - left (0 for img, non-0 for flow)
+\t--saveType, --st (value:jpg)
+\t\tsave format type (png/h5/jpg)
+\t-v, --verbose
+\t\tverbose
+
+\tinput
+\t\tfilename of video or folder of frames or a list.txt of those
+"""
+
+
+@pytest.fixture(scope="module")
+def built():
+    r = subprocess.run(["make", "-C", ROOT, "host"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return BIN
+
+
+@pytest.fixture(scope="module")
+def harness(built):
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libhost_harness.so")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-o", so,
+           os.path.join(ROOT, "tests", "host_harness.cpp"), os.path.join(ROOT, "build", "libzzdenseflow.a"),
+           "-L" + os.path.join(ROOT, "denseflow_amd", "lib"), "-ldfx", "-lpthread",
+           "-Wl,-rpath," + os.path.join(ROOT, "denseflow_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return C.CDLL(so)
+
+
+def write_y4m(path, frames):
+    h, w = frames[0].shape
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{w} H{h} F30:1 Ip A1:1 Cmono\n".encode())
+        for fr in frames:
+            f.write(b"FRAME\n")
+            f.write(np.ascontiguousarray(fr, np.uint8).tobytes())
+
+
+def test_help_text_matches_reference_readme(built):
+    # README.md:109-143 of the reference, plus the one added key (-g)
+    for args in ([], ["-h"], ["--help", "x.mp4"]):
+        r = subprocess.run([built] + args, capture_output=True, text=True)
+        assert r.returncode == 0
+        assert r.stdout == HELP_GOLDEN
+
+
+def test_cli_error_behaviour(built, tmp_path):
+    clip = tmp_path / "a.y4m"
+    write_y4m(clip, SynthClip(32, 24, 1).frames(2))
+    r = subprocess.run([built, str(clip), "-o=" + str(tmp_path), "-s=1", "-a=lk"], capture_output=True, text=True)
+    assert r.returncode == 1 and "lk not supported!" in r.stdout and "check init param error." in r.stdout
+    r = subprocess.run([built, str(clip), "-o=" + str(tmp_path), "-s=1", "-b=0"], capture_output=True, text=True)
+    assert r.returncode == 1 and "bound should > 0!" in r.stdout
+    r = subprocess.run([built, str(clip), "-o=" + str(tmp_path), "-s=1", "-st=gif"], capture_output=True, text=True)
+    assert "only jpg/png/h5 are supported (no gif) for output" in r.stdout
+    r = subprocess.run([built, str(clip), "-o=" + str(tmp_path), "-s=abc"], capture_output=True, text=True)
+    assert r.returncode == 0 and "can not convert" in r.stdout  # parse errors: print, exit 0 (tools/denseflow.cpp:30-33)
+    r = subprocess.run([built, str(tmp_path / "missing.y4m"), "-o=" + str(tmp_path), "-s=1"], capture_output=True,
+                       text=True)
+    assert r.returncode == 1 and "does not exist!" in r.stdout
+    if not os.path.exists("/dev/kfd"):  # no GPU: the flow mode must fail loudly, never compute on the CPU
+        r = subprocess.run([built, str(clip), "-o=" + str(tmp_path), "-s=1"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU fallback" in r.stdout
+
+
+def test_frame_extraction_mode_writes_decodable_jpegs(built, tmp_path):
+    from PIL import Image
+
+    frames = SynthClip(96, 64, 5).frames(3)
+    clip = tmp_path / "vid.y4m"
+    write_y4m(clip, frames)
+    r = subprocess.run([built, str(clip), "-o=" + str(tmp_path / "out"), "-s=0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "1 videos (3 frames, 0 tvl1 flows) processed" in r.stdout
+    for i, fr in enumerate(frames):
+        img = np.array(Image.open(tmp_path / "out" / "vid" / f"img_{i:05d}.jpg"))
+        assert img.shape == fr.shape
+        mse = np.mean((img.astype(np.float64) - fr) ** 2)
+        assert 10 * np.log10(255 ** 2 / mse) > 38  # quality 95
+
+
+def test_quantisation_cast_formula(harness):
+    rng = np.random.default_rng(0)
+    w, h, bound = 37, 11, 20
+    fx = rng.uniform(-30, 30, (h, w)).astype(np.float32)
+    fy = rng.uniform(-30, 30, (h, w)).astype(np.float32)
+    fx[0, :4] = [-20, 20, 0, 20.0001]
+    ox = np.zeros((h, w), np.uint8)
+    oy = np.zeros((h, w), np.uint8)
+    harness.hh_quantise(fx.ctypes.data_as(C.c_void_p), fy.ctypes.data_as(C.c_void_p), w, h, bound,
+                        ox.ctypes.data_as(C.c_void_p), oy.ctypes.data_as(C.c_void_p))
+
+    def cast(v):  # src/common.cpp:6 of the reference: double arithmetic, cvRound = round-half-even
+        v = v.astype(np.float64)
+        q = np.rint(255 * (v + bound) / (2 * bound))
+        return np.where(v > bound, 255, np.where(v < -bound, 0, q)).astype(np.uint8)
+
+    assert np.array_equal(ox, cast(fx)) and np.array_equal(oy, cast(fy))
+    assert list(ox[0, :4]) == [0, 255, 128, 255]
+
+
+def test_png_and_jpeg_encoders_round_trip(harness):
+    from PIL import Image
+
+    rng = np.random.default_rng(1)
+    w, h = 70, 45
+    gray = (rng.uniform(0, 1, (h, w)) * 255).astype(np.uint8)
+    buf = np.zeros(1 << 20, np.uint8)
+    n = harness.hh_encode_jpeg(gray.ctypes.data_as(C.c_void_p), w, h, 100, buf.ctypes.data_as(C.c_void_p), buf.size)
+    assert n > 0
+    dec = np.array(Image.open(io.BytesIO(buf[:n].tobytes())))
+    assert dec.shape == (h, w) and np.abs(dec.astype(int) - gray).max() <= 3
+    fx = rng.uniform(-3, 3, (h, w)).astype(np.float32)
+    fy = rng.uniform(-1, 1, (h, w)).astype(np.float32)
+    n = harness.hh_encode_flow_png(fx.ctypes.data_as(C.c_void_p), fy.ctypes.data_as(C.c_void_p), w, h,
+                                   buf.ctypes.data_as(C.c_void_p), buf.size)
+    assert n > 0
+    png = np.array(Image.open(io.BytesIO(buf[:n].tobytes())))  # RGB; the shell wrote B=x, G=y, R=bound/4
+    assert png.shape == (h, w, 3)
+    bx = int(png[0, 0, 0]) * 4
+    assert bx in (4, 12)  # ceil(3*128/127/4)*4 = 4, bumped by 4 only if divisible by 8
+    x_rec = (png[..., 2].astype(np.float64) - 128) * (bx / 128.0)
+    assert np.abs(x_rec - fx).max() <= bx / 128.0
+
+
+@pytest.mark.gpu
+def test_operator_matches_oracle_on_gpu(harness, oracle):
+    w, h, n, step = 96, 64, 5, 1
+    frames = np.stack(SynthClip(w, h, 5).frames(n))
+    flows = np.zeros((n - 1, h, w, 2), np.float32)
+    err = C.create_string_buffer(512)
+    harness.hh_calc_optflows_imp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_void_p,
+                                             C.c_char_p, C.c_int]
+    for algo, fn in (("tvl1", oracle.tvl1_calc), ("farn", oracle.farneback_calc)):
+        m = harness.hh_calc_optflows_imp(frames.ctypes.data, n, w, h, algo.encode(), step, flows.ctypes.data, err, 512)
+        assert m == n - 1, err.value
+        for i in range(m):
+            assert np.max(np.abs(flows[i] - fn(frames[i], frames[i + 1]))) <= 1e-3
+    m = harness.hh_calc_optflows_imp(frames.ctypes.data, n, w, h, b"nv", step, flows.ctypes.data, err, 512)
+    assert m == -1 and err.value == b"NV hardware flow not enabled, pls recompile"
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_on_gpu(built, oracle, tmp_path):
+    """BASELINE config 1 shape: a 224x224 pair sequence, -a=tvl1 -s=1 -b=20, files named like the reference's."""
+    from PIL import Image
+
+    w, h, n = 224, 224, 4
+    frames = SynthClip(w, h, 1).frames(n)
+    clip = tmp_path / "clip.y4m"
+    write_y4m(clip, frames)
+    lst = tmp_path / "list.txt"
+    lst.write_text(str(clip) + "\n")
+    r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / "out"), "-a=tvl1", "-s=1", "-b=20"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"1 videos ({n} frames, {n - 1} tvl1 flows) processed" in r.stdout and "done video" in r.stdout
+    assert (tmp_path / "out" / ".done" / "clip").is_file()
+    for i in range(n - 1):
+        ref = oracle.tvl1_calc(frames[i], frames[i + 1])
+        for c, name in enumerate(("flow_x", "flow_y")):
+            img = np.array(Image.open(tmp_path / "out" / "clip" / f"{name}_{i:05d}.jpg")).astype(np.float64)
+            q = np.rint(255 * (np.clip(ref[..., c].astype(np.float64), -20, 20) + 20) / 40)
+            assert np.abs(img - q).mean() < 1.0  # JPEG q95 of the quantised oracle flow
+    # second run: the .done marker makes it a no-op (resume)
+    r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / "out"), "-a=tvl1", "-s=1", "-b=20", "-v"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0 and "skip" in r.stdout
