@@ -74,6 +74,8 @@ def lib():
     if not os.path.exists(_LIB_PATH):
         build()
     L = C.CDLL(_LIB_PATH)
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    L.orc_get_max_threads.restype = C.c_int
     L.orc_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
     L.orc_tvl1_calc.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, C.POINTER(Tvl1Params), _f32p,
                                 C.POINTER(Tvl1Trace)]
@@ -95,18 +97,30 @@ def lib():
     return L
 
 
+def _pick_threads(h: int, w: int, threads):
+    """One thread per ~16k pixels unless the caller fixes it (bench: all cores).  The row loops are
+    short; on a 256-thread host the fork/join cost of every tiny parallel region dominates otherwise."""
+    L = lib()
+    if threads is None:
+        threads = max(1, min((h * w) // 16384, os.cpu_count() or 1))
+    L.orc_set_num_threads(int(threads))
+    return L.orc_get_max_threads()
+
+
 def tvl1_default_params() -> Tvl1Params:
     p = Tvl1Params()
     lib().orc_tvl1_default_params(C.byref(p))
     return p
 
 
-def tvl1_calc(frame0: np.ndarray, frame1: np.ndarray, params: Tvl1Params | None = None, want_trace: bool = False):
+def tvl1_calc(frame0: np.ndarray, frame1: np.ndarray, params: Tvl1Params | None = None, want_trace: bool = False,
+              threads=None):
     """cv::cuda::OpticalFlowDual_TVL1::calc restatement. Returns flow (H,W,2) [, trace]."""
     f0 = np.ascontiguousarray(frame0, dtype=np.uint8)
     f1 = np.ascontiguousarray(frame1, dtype=np.uint8)
     assert f0.shape == f1.shape and f0.ndim == 2
     h, w = f0.shape
+    _pick_threads(h, w, threads)
     flow = np.empty((h, w, 2), dtype=np.float32)
     trace = Tvl1Trace()
     rc = lib().orc_tvl1_calc(f0, w, f1, w, w, h, C.byref(params) if params is not None else None, flow,
@@ -145,11 +159,13 @@ def farneback_default_params() -> FarnebackParams:
     return p
 
 
-def farneback_calc(frame0: np.ndarray, frame1: np.ndarray, params: FarnebackParams | None = None) -> np.ndarray:
+def farneback_calc(frame0: np.ndarray, frame1: np.ndarray, params: FarnebackParams | None = None,
+                   threads=None) -> np.ndarray:
     f0 = np.ascontiguousarray(frame0, dtype=np.uint8)
     f1 = np.ascontiguousarray(frame1, dtype=np.uint8)
     assert f0.shape == f1.shape and f0.ndim == 2
     h, w = f0.shape
+    _pick_threads(h, w, threads)
     flow = np.empty((h, w, 2), dtype=np.float32)
     rc = lib().orc_farneback_calc(f0, w, f1, w, w, h, C.byref(params) if params is not None else None, flow)
     if rc != 0:

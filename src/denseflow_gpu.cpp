@@ -10,9 +10,21 @@
 #include "dense_flow.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 
 #include "utils.h"
+
+// DF_TRACE=1: stage-by-stage trace on stderr (debugging aid; the reference has none)
+static const bool g_trace = std::getenv("DF_TRACE") != nullptr;
+#define TRACE(...)                                                                                              \
+    do {                                                                                                        \
+        if (g_trace) {                                                                                          \
+            fprintf(stderr, "[denseflow] " __VA_ARGS__);                                                        \
+            fputc('\n', stderr);                                                                                \
+            fflush(stderr);                                                                                     \
+        }                                                                                                       \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------------ queue
 
@@ -184,6 +196,8 @@ int DenseFlow::load_frames_video(VideoCapture &video_stream, vector<path> &frame
         if (verbose)
             cout << "push frames gray, video_flow_idx " << video_flow_idx << ", batch_size " << frames_gray.size()
                  << endl;
+        TRACE("load: push %zu frames, base %d, last_buffer %d, final %d", padded.size(), video_flow_idx, (int)!is_open,
+              (int)(is_last && !is_open));
         frames_gray_queue.push(FlowBuffer(padded, output_dir, video_flow_idx, !is_open), is_last && !is_open);
         // the last |step| frames are needed again as the head of the next buffer (:204-207)
         padding.assign(padded.end() - std::min<size_t>(astep, padded.size()), padded.end());
@@ -251,6 +265,7 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
             throw std::runtime_error(dfx_algo_error_message(rc, algorithm.c_str(), msg, sizeof msg));
         }
         const Size sz = frames_gray.item_data[0].size();
+        TRACE("calc: %d frames -> %d flows, %dx%d, algorithm %s", N, M, sz.width, sz.height, algorithm.c_str());
         if (!dfx_ || !(sz == dfx_size_)) { // sized per video; reused across its FlowBuffers
             if (dfx_)
                 dfx_destroy(dfx_);
@@ -269,6 +284,7 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
         }
         if (dfx_calc_batch(dfx_, in.data(), frames_gray.item_data[0].step, N, step, out.data(), flows[0].step) != DFX_OK)
             throw std::runtime_error(dfx_last_error(dfx_));
+        TRACE("calc: dfx_calc_batch done");
         total_flows += M;
     }
     if (verbose)
@@ -296,6 +312,7 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
         bool is_final = false;
         FlowBuffer flow_buffer = flows_queue.pop(&is_final);
         const int M = (int)flow_buffer.item_data.size();
+        TRACE("save: %d flows, base %d, final %d", M, flow_buffer.base_start, (int)is_final);
         if (save_type == "jpg") {
             vector<vector<uchar>> output_x, output_y;
             for (int i = 0; i < M; ++i) {
@@ -408,8 +425,11 @@ void DenseFlow::launch(bool use_frames, string save_type, bool verbose) {
     thread t_calc(guarded(1, [&] { calc_optflows(false); }));
     thread t_save(guarded(2, [&] { encode_save(save_type, false); }));
     t_load.join();
+    TRACE("launch: load joined");
     t_calc.join();
+    TRACE("launch: calc joined");
     t_save.join();
+    TRACE("launch: save joined");
     for (auto &e : err)
         if (e)
             std::rethrow_exception(e);

@@ -29,9 +29,15 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def oracle():
+    import numpy as np
+
     from oracle import oracle_py
 
     oracle_py.build()
+    # Create the OpenMP worker pool now, before any test initialises the HIP runtime in this process
+    # (observed on the MI355X box: the first parallel region after HIP start-up can stall for minutes).
+    z = np.zeros((160, 160), np.uint8)
+    oracle_py.tvl1_calc(z, z, threads=os.cpu_count() or 1)
     return oracle_py
 
 

@@ -5,6 +5,7 @@
 // bare `-k` is a boolean presence, other tokens are positional).  One key is added:
 // `-g, --gpus` (number of GPUs to shard a list.txt over, default 1).
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 
 #include "dense_flow.h"
@@ -159,7 +160,8 @@ int main(int argc, char **argv) {
             return 0;
         }
 
-        Mat::setPageLocked(true); // reference: Mat::setDefaultAllocator(PAGE_LOCKED) (:49)
+        // reference: Mat::setDefaultAllocator(PAGE_LOCKED) (:49); DF_NO_PINNED=1 keeps pageable buffers
+        Mat::setPageLocked(std::getenv("DF_NO_PINNED") == nullptr);
 
         vector<path> video_paths, output_dirs;
         bool is_record = false;
