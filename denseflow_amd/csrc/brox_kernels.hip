@@ -1,0 +1,341 @@
+// brox_kernels.hip — hand-written gfx950 kernels for the -a=brox path.
+//
+// Replaces cv::cuda::BroxOpticalFlow::calc as the reference calls it (/root/reference/src/denseflow_gpu.cpp:303,
+// :332-334): the NCVBroxOpticalFlow kernels (derivative row/column filters, prepare_sor_stage_1_tex,
+// prepare_sor_stage_2, sor_pass<red/black>, add, resize, scale) plus the 1/255 convertTo.
+// The algorithm is the one DEFINED in oracle/brox_oracle.h (upstream details are only partly known:
+// SURVEY.md Appendix C, confidence LOW; reference parity is unpinned).  Every expression below is written in
+// the oracle's operation order and the file is compiled with -ffp-contract=off, so results are bit-identical
+// to the oracle.
+#include <hip/hip_runtime.h>
+
+#include "brox_kernels.h"
+
+#define BROX_EPS2 1e-6f
+
+static inline dim3 bgrid(int w, int h, int z) { return dim3((w + 63) / 64, (h + 3) / 4, z); }
+
+__device__ __forceinline__ int mirror_idx(int i, int n) { // edge-duplicating mirror, any offset
+    const int p = 2 * n;
+    int m = i % p;
+    if (m < 0)
+        m += p;
+    return m < n ? m : p - 1 - m;
+}
+__device__ __forceinline__ float inv_sqrtf_ieee(float s) { return 1.0f / sqrtf(s); }
+__device__ __forceinline__ float brox_bicubic_w(float x_) {
+    const float x = fabsf(x_);
+    const float near = x * x * (1.5f * x - 2.5f) + 1.0f;
+    const float far = x * (x * (-0.5f * x + 2.5f) - 4.0f) + 2.0f;
+    return x <= 1.0f ? near : (x < 2.0f ? far : 0.0f);
+}
+__device__ __forceinline__ float *bplane(const BroxLevelCtx &c, int pair, int plane) {
+    return c.planes + (long long)pair * c.slot_stride + (long long)plane * c.plane_stride;
+}
+__device__ __forceinline__ const float *fplane(const BroxLevelCtx &c, int slot, int plane) {
+    return c.frames + (long long)slot * c.frame_stride + (long long)plane * c.pyr_elems + c.lvl_off;
+}
+
+// ------------------------------------------------------------------------------------------------ frames
+
+__global__ __launch_bounds__(256) void k_brox_u8_to_f32(const unsigned char *src, long long src_frame_stride,
+                                                        long long src_pitch, const int *frame_slots, float *frames,
+                                                        long long frame_stride, int w, int h, int pitch, float scale) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h)
+        return;
+    const int z = blockIdx.z;
+    frames[(long long)frame_slots[z] * frame_stride + (long long)y * pitch + x] =
+        (float)src[(long long)z * src_frame_stride + (long long)y * src_pitch + x] * scale;
+}
+
+// area-averaging ("supersample") down-sampling of plane I from level l-1 to level l
+__global__ __launch_bounds__(256) void k_brox_downsample(float *frames, long long frame_stride, const int *frame_slots,
+                                                         long long src_off, int sw, int sh, int spitch,
+                                                         long long dst_off, int dw, int dh, int dpitch, float factor) {
+    const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ix >= dw || iy >= dh)
+        return;
+    float *base = frames + (long long)frame_slots[blockIdx.z] * frame_stride;
+    const float *src = base + src_off;
+    const float s = 1.0f / factor;
+    const float y = s * (float)iy, x = s * (float)ix;
+    const int yb = (int)floorf(y), ye = (int)ceilf(y + s);
+    const int xb = (int)floorf(x), xe = (int)ceilf(x + s);
+    float sum = 0.f, wsum = 0.f;
+    for (int cy = yb; cy < ye; ++cy) {
+        const float wy = fminf((float)cy + 1.0f, y + s) - fmaxf((float)cy, y);
+        const float *row = src + (long long)min(cy, sh - 1) * spitch;
+        for (int cx = xb; cx < xe; ++cx) {
+            const float wx = fminf((float)cx + 1.0f, x + s) - fmaxf((float)cx, x);
+            const float w = wx * wy;
+            sum = sum + w * row[min(cx, sw - 1)];
+            wsum = wsum + w;
+        }
+    }
+    base[dst_off + (long long)iy * dpitch + ix] = sum / wsum;
+}
+
+__global__ __launch_bounds__(256) void k_brox_deriv(float *frames, long long frame_stride, const int *frame_slots,
+                                                    long long src_off, long long dst_off, int w, int h, int pitch,
+                                                    int axis) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h)
+        return;
+    float *base = frames + (long long)frame_slots[blockIdx.z] * frame_stride;
+    const float *src = base + src_off;
+    const float kD[5] = {1.0f, -8.0f, 0.0f, 8.0f, -1.0f};
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float v = axis == 0 ? src[(long long)y * pitch + mirror_idx(x + k - 2, w)]
+                                  : src[(long long)mirror_idx(y + k - 2, h) * pitch + x];
+        s = s + v * kD[k];
+    }
+    base[dst_off + (long long)y * pitch + x] = s * (1.0f / 12.0f);
+}
+
+// ------------------------------------------------------------------------------------------------ per pair
+
+__global__ __launch_bounds__(256) void k_brox_level_init(BroxLevelCtx c, int uv_set, int zero_uv) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.w || y >= c.h)
+        return;
+    const int b = blockIdx.z;
+    const long long o = (long long)y * c.pitch + x;
+    bplane(c, b, BROX_PL_DU)[o] = 0.0f;
+    bplane(c, b, BROX_PL_DV)[o] = 0.0f;
+    if (zero_uv) {
+        bplane(c, b, BROX_PL_U0 + 2 * uv_set)[o] = 0.0f;
+        bplane(c, b, BROX_PL_V0 + 2 * uv_set)[o] = 0.0f;
+    }
+}
+
+struct BlTap {
+    long long i00, i01, i10, i11;
+    float ax, ay;
+};
+__device__ __forceinline__ BlTap bl_setup(float fx, float fy, int w, int h, int pitch) {
+    BlTap t;
+    fx = fminf(fmaxf(fx, -1.0e6f), 1.0e6f);
+    fy = fminf(fmaxf(fy, -1.0e6f), 1.0e6f);
+    const float x0 = floorf(fx), y0 = floorf(fy);
+    t.ax = fx - x0;
+    t.ay = fy - y0;
+    const int xa = mirror_idx((int)x0, w), xb = mirror_idx((int)x0 + 1, w);
+    const int ya = mirror_idx((int)y0, h), yb = mirror_idx((int)y0 + 1, h);
+    t.i00 = (long long)ya * pitch + xa;
+    t.i01 = (long long)ya * pitch + xb;
+    t.i10 = (long long)yb * pitch + xa;
+    t.i11 = (long long)yb * pitch + xb;
+    return t;
+}
+__device__ __forceinline__ float bl_sample(const float *p, const BlTap &t) {
+    const float a = (1.0f - t.ax) * p[t.i00] + t.ax * p[t.i01];
+    const float b = (1.0f - t.ax) * p[t.i10] + t.ax * p[t.i11];
+    return (1.0f - t.ay) * a + t.ay * b;
+}
+
+// stage 1: data-term coefficients and staggered diffusivities (brox_oracle.h, step 3b)
+__global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.w || y >= c.h)
+        return;
+    const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
+    const PairDesc pd = c.pairs[b];
+    const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
+    const float *DU = bplane(c, b, BROX_PL_DU), *DV = bplane(c, b, BROX_PL_DV);
+    const long long o = (long long)y * pitch + x;
+    const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
+#define WU(xx, yy) (u[(long long)(yy)*pitch + (xx)] + DU[(long long)(yy)*pitch + (xx)])
+#define WV(xx, yy) (v[(long long)(yy)*pitch + (xx)] + DV[(long long)(yy)*pitch + (xx)])
+    const BlTap t = bl_setup((float)x + u[o], (float)y + v[o], w, h, pitch);
+    const float I1w = bl_sample(fplane(c, pd.frame_b, BROX_FP_I), t);
+    const float Ixw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DX), t);
+    const float Iyw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DY), t);
+    const float Ixxw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DXX), t);
+    const float Ixyw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DXY), t);
+    const float Iyyw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DYY), t);
+    const float Iz = I1w - fplane(c, pd.frame_a, BROX_FP_I)[o];
+    const float Ixz = Ixw - fplane(c, pd.frame_a, BROX_FP_DX)[o];
+    const float Iyz = Iyw - fplane(c, pd.frame_a, BROX_FP_DY)[o];
+    const float du = DU[o], dv = DV[o];
+    const float gamma = c.gamma;
+    const float q0 = Iz + (Ixw * du + Iyw * dv);
+    const float q1 = Ixz + (Ixxw * du + Ixyw * dv);
+    const float q2 = Iyz + (Ixyw * du + Iyyw * dv);
+    const float psi = (0.5f * inv_sqrtf_ieee((q0 * q0 + gamma * (q1 * q1 + q2 * q2)) + BROX_EPS2)) / c.alpha;
+    bplane(c, b, BROX_PL_NDUDV)[o] = psi * (Ixw * Iyw + gamma * (Ixxw * Ixyw + Ixyw * Iyyw));
+    bplane(c, b, BROX_PL_IDU)[o] = psi * (Ixw * Ixw + gamma * (Ixyw * Ixyw + Ixxw * Ixxw));
+    bplane(c, b, BROX_PL_IDV)[o] = psi * (Iyw * Iyw + gamma * (Ixyw * Ixyw + Iyyw * Iyyw));
+    bplane(c, b, BROX_PL_NU)[o] = psi * (Ixw * Iz + gamma * (Ixxw * Ixz + Ixyw * Iyz));
+    bplane(c, b, BROX_PL_NV)[o] = psi * (Iyw * Iz + gamma * (Iyyw * Iyz + Ixyw * Ixz));
+    float gx = 0.0f, gy = 0.0f;
+    if (x > 0) {
+        const float ux = WU(x, y) - WU(xm, y), vx = WV(x, y) - WV(xm, y);
+        const float uy = 0.25f * (((WU(x, yp) + WU(xm, yp)) - WU(x, ym)) - WU(xm, ym));
+        const float vy = 0.25f * (((WV(x, yp) + WV(xm, yp)) - WV(x, ym)) - WV(xm, ym));
+        gx = 0.5f * inv_sqrtf_ieee((((ux * ux + uy * uy) + vx * vx) + vy * vy) + BROX_EPS2);
+    }
+    if (y > 0) {
+        const float uy = WU(x, y) - WU(x, ym), vy = WV(x, y) - WV(x, ym);
+        const float ux = 0.25f * (((WU(xp, y) + WU(xp, ym)) - WU(xm, y)) - WU(xm, ym));
+        const float vx = 0.25f * (((WV(xp, y) + WV(xp, ym)) - WV(xm, y)) - WV(xm, ym));
+        gy = 0.5f * inv_sqrtf_ieee((((ux * ux + uy * uy) + vx * vx) + vy * vy) + BROX_EPS2);
+    }
+    bplane(c, b, BROX_PL_GX)[o] = gx;
+    bplane(c, b, BROX_PL_GY)[o] = gy;
+#undef WU
+#undef WV
+}
+
+__global__ __launch_bounds__(256) void k_brox_stage2(BroxLevelCtx c) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.w || y >= c.h)
+        return;
+    const int b = blockIdx.z;
+    const long long o = (long long)y * c.pitch + x;
+    const float *GX = bplane(c, b, BROX_PL_GX), *GY = bplane(c, b, BROX_PL_GY);
+    const float gl = GX[o], gr = (x + 1 < c.w) ? GX[o + 1] : 0.0f;
+    const float gd = GY[o], gu = (y + 1 < c.h) ? GY[o + c.pitch] : 0.0f;
+    const float gs = ((gl + gr) + gd) + gu;
+    float *IDU = bplane(c, b, BROX_PL_IDU), *IDV = bplane(c, b, BROX_PL_IDV);
+    IDU[o] = 1.0f / (IDU[o] + gs);
+    IDV[o] = 1.0f / (IDV[o] + gs);
+}
+
+// one red/black SOR half-sweep: only pixels with (x + y) % 2 == color are updated (in place; their four
+// neighbours have the other colour and are not touched by this launch)
+__global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, int color) {
+    const int xh = blockIdx.x * 64 + (threadIdx.x & 63); // half-resolution column index
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= c.h)
+        return;
+    const int x = 2 * xh + ((y + color) & 1);
+    if (x >= c.w)
+        return;
+    const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
+    const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
+    float *DU = bplane(c, b, BROX_PL_DU), *DV = bplane(c, b, BROX_PL_DV);
+    const float *GX = bplane(c, b, BROX_PL_GX), *GY = bplane(c, b, BROX_PL_GY);
+    const long long o = (long long)y * pitch + x;
+    const long long ol = (long long)y * pitch + max(x - 1, 0), orr = (long long)y * pitch + min(x + 1, w - 1);
+    const long long od = (long long)max(y - 1, 0) * pitch + x, ou = (long long)min(y + 1, h - 1) * pitch + x;
+    const float gl = GX[o], gr = (x + 1 < w) ? GX[o + 1] : 0.0f;
+    const float gd = GY[o], gu = (y + 1 < h) ? GY[o + pitch] : 0.0f;
+    const float gs = ((gl + gr) + gd) + gu;
+    const float su =
+        (((gl * (u[ol] + DU[ol]) + gr * (u[orr] + DU[orr])) + gd * (u[od] + DU[od])) + gu * (u[ou] + DU[ou])) - gs * u[o];
+    const float sv =
+        (((gl * (v[ol] + DV[ol]) + gr * (v[orr] + DV[orr])) + gd * (v[od] + DV[od])) + gu * (v[ou] + DV[ou])) - gs * v[o];
+    const float du = DU[o], dv = DV[o];
+    const float ndudv = bplane(c, b, BROX_PL_NDUDV)[o];
+    const float omega = c.omega;
+    const float du_n =
+        (1.0f - omega) * du + omega * (bplane(c, b, BROX_PL_IDU)[o] * ((su - bplane(c, b, BROX_PL_NU)[o]) - ndudv * dv));
+    const float dv_n =
+        (1.0f - omega) * dv + omega * (bplane(c, b, BROX_PL_IDV)[o] * ((sv - bplane(c, b, BROX_PL_NV)[o]) - ndudv * du_n));
+    DU[o] = du_n;
+    DV[o] = dv_n;
+}
+
+__global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int uv_set) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.w || y >= c.h)
+        return;
+    const int b = blockIdx.z;
+    const long long o = (long long)y * c.pitch + x;
+    float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
+    u[o] = u[o] + bplane(c, b, BROX_PL_DU)[o];
+    v[o] = v[o] + bplane(c, b, BROX_PL_DV)[o];
+}
+
+__global__ __launch_bounds__(256) void k_brox_prolongate(BroxLevelCtx c, int uv_set, int dw, int dh, int dpitch,
+                                                         float factor, float mul) {
+    const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ix >= dw || iy >= dh)
+        return;
+    const int b = blockIdx.z, sw = c.w, sh = c.h;
+    const float y = (float)iy * factor, x = (float)ix * factor;
+    const int y0 = max((int)ceilf(y - 2.0f), 0), y1 = min((int)floorf(y + 2.0f), sh - 1);
+    const int x0 = max((int)ceilf(x - 2.0f), 0), x1 = min((int)floorf(x + 2.0f), sw - 1);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float *src = bplane(c, b, BROX_PL_U0 + 2 * uv_set + k);
+        float sum = 0.f, wsum = 0.f;
+        for (int cy = y0; cy <= y1; ++cy) {
+            const float wy = brox_bicubic_w(y - (float)cy);
+            for (int cx = x0; cx <= x1; ++cx) {
+                const float wgt = brox_bicubic_w(x - (float)cx) * wy;
+                sum = sum + wgt * src[(long long)cy * c.pitch + cx];
+                wsum = wsum + wgt;
+            }
+        }
+        const float val = (wsum == 0.0f) ? 0.0f : sum / wsum;
+        bplane(c, b, BROX_PL_U0 + 2 * (uv_set ^ 1) + k)[(long long)iy * dpitch + ix] = val * mul;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_brox_merge(BroxLevelCtx c, int uv_set, float *out, long long out_stride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= c.w || y >= c.h)
+        return;
+    const int b = blockIdx.z;
+    const long long o = (long long)y * c.pitch + x;
+    float2 v;
+    v.x = bplane(c, b, BROX_PL_U0 + 2 * uv_set)[o];
+    v.y = bplane(c, b, BROX_PL_V0 + 2 * uv_set)[o];
+    reinterpret_cast<float2 *>(out + (long long)b * out_stride)[(long long)y * c.w + x] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+
+void brox_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long src_frame_stride, long long src_pitch,
+                           const int *frame_slots, int n_frames, float *frames, long long frame_stride, int w, int h,
+                           int pitch, float scale) {
+    hipLaunchKernelGGL(k_brox_u8_to_f32, bgrid(w, h, n_frames), dim3(256), 0, s, src, src_frame_stride, src_pitch,
+                       frame_slots, frames, frame_stride, w, h, pitch, scale);
+}
+void brox_launch_downsample(hipStream_t s, float *frames, long long frame_stride, const int *frame_slots,
+                            int n_frames, long long src_off, int sw, int sh, int spitch, long long dst_off, int dw,
+                            int dh, int dpitch, float factor) {
+    hipLaunchKernelGGL(k_brox_downsample, bgrid(dw, dh, n_frames), dim3(256), 0, s, frames, frame_stride, frame_slots,
+                       src_off, sw, sh, spitch, dst_off, dw, dh, dpitch, factor);
+}
+void brox_launch_deriv(hipStream_t s, float *frames, long long frame_stride, const int *frame_slots, int n_frames,
+                       long long src_off, long long dst_off, int w, int h, int pitch, int axis) {
+    hipLaunchKernelGGL(k_brox_deriv, bgrid(w, h, n_frames), dim3(256), 0, s, frames, frame_stride, frame_slots, src_off,
+                       dst_off, w, h, pitch, axis);
+}
+void brox_launch_level_init(hipStream_t s, const BroxLevelCtx &c, int uv_set, int zero_uv) {
+    hipLaunchKernelGGL(k_brox_level_init, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, zero_uv);
+}
+void brox_launch_stage1(hipStream_t s, const BroxLevelCtx &c, int uv_set) {
+    hipLaunchKernelGGL(k_brox_stage1, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set);
+}
+void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c) {
+    hipLaunchKernelGGL(k_brox_stage2, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c);
+}
+void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int color) {
+    hipLaunchKernelGGL(k_brox_sor, bgrid((c.w + 1) / 2, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, color);
+}
+void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set) {
+    hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set);
+}
+void brox_launch_prolongate(hipStream_t s, const BroxLevelCtx &c, int uv_set, int dw, int dh, int dpitch, float factor,
+                            float mul) {
+    hipLaunchKernelGGL(k_brox_prolongate, bgrid(dw, dh, c.n_pairs), dim3(256), 0, s, c, uv_set, dw, dh, dpitch, factor,
+                       mul);
+}
+void brox_launch_merge(hipStream_t s, const BroxLevelCtx &c, int uv_set, float *out, long long out_stride) {
+    hipLaunchKernelGGL(k_brox_merge, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, out, out_stride);
+}

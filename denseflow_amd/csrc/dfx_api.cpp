@@ -235,7 +235,7 @@ int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height
         else if (algo == DFX_ALGO_FARN)
             c->engine = dfx_make_farneback_engine(c);
         else
-            return dfx_fail(c, DFX_ERR_UNSUPPORTED, "-a=brox is not implemented yet in this build");
+            c->engine = dfx_make_brox_engine(c);
         return c->engine->create();
     };
     const int rc = init();

@@ -92,3 +92,4 @@ template <class T> inline void dfx_free_host(T *&p) {
 
 AlgoEngine *dfx_make_tvl1_engine(dfx_context *c);
 AlgoEngine *dfx_make_farneback_engine(dfx_context *c);
+AlgoEngine *dfx_make_brox_engine(dfx_context *c);

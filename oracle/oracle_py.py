@@ -93,6 +93,12 @@ def lib():
         L.orc_farneback_calc.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int,
                                          C.POINTER(FarnebackParams), _f32p]
         L.orc_farneback_calc.restype = C.c_int
+    if hasattr(L, "orc_brox_calc"):
+        L.orc_brox_default_params.argtypes = [C.POINTER(BroxParams)]
+        L.orc_brox_calc.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, C.POINTER(BroxParams), _f32p]
+        L.orc_brox_calc.restype = C.c_int
+        L.orc_brox_pyramid_sizes.argtypes = [C.c_int, C.c_int, C.POINTER(BroxParams), C.POINTER(C.c_int), C.c_int]
+        L.orc_brox_pyramid_sizes.restype = C.c_int
     _lib = L
     return L
 
@@ -170,4 +176,45 @@ def farneback_calc(frame0: np.ndarray, frame1: np.ndarray, params: FarnebackPara
     rc = lib().orc_farneback_calc(f0, w, f1, w, w, h, C.byref(params) if params is not None else None, flow)
     if rc != 0:
         raise ValueError("orc_farneback_calc rejected the parameters")
+    return flow
+
+
+# ------------------------------------------------------------------------------ Brox
+
+class BroxParams(C.Structure):
+    _fields_ = [
+        ("alpha", C.c_float),
+        ("gamma", C.c_float),
+        ("scale_factor", C.c_float),
+        ("inner_iterations", C.c_int),
+        ("outer_iterations", C.c_int),
+        ("solver_iterations", C.c_int),
+    ]
+
+
+def brox_default_params() -> BroxParams:
+    p = BroxParams()
+    lib().orc_brox_default_params(C.byref(p))
+    return p
+
+
+def brox_pyramid_sizes(w: int, h: int, params: BroxParams | None = None):
+    p = params if params is not None else brox_default_params()
+    buf = (C.c_int * 256)()
+    n = lib().orc_brox_pyramid_sizes(w, h, C.byref(p), buf, 128)
+    return [(buf[2 * i], buf[2 * i + 1]) for i in range(n)]
+
+
+def brox_calc(frame0: np.ndarray, frame1: np.ndarray, params: BroxParams | None = None, threads=None) -> np.ndarray:
+    """cv::cuda::BroxOpticalFlow restatement as DEFINED in oracle/brox_oracle.h (u8 frames in, the
+    1/255 pre-scale of src/denseflow_gpu.cpp:332-333 is part of it)."""
+    f0 = np.ascontiguousarray(frame0, dtype=np.uint8)
+    f1 = np.ascontiguousarray(frame1, dtype=np.uint8)
+    assert f0.shape == f1.shape and f0.ndim == 2
+    h, w = f0.shape
+    _pick_threads(h, w, threads)
+    flow = np.empty((h, w, 2), dtype=np.float32)
+    rc = lib().orc_brox_calc(f0, w, f1, w, w, h, C.byref(params) if params is not None else None, flow)
+    if rc != 0:
+        raise ValueError("orc_brox_calc rejected the parameters")
     return flow

@@ -1,0 +1,78 @@
+"""GPU parity tests for -a=brox (through the C ABI) against the CPU oracle that DEFINES the algorithm
+(oracle/brox_oracle.h; reference parity unpinned).  Tolerance 1e-3 max-abs as for
+the other algorithms; the device evaluates the oracle's expressions in the same order, so exact equality
+is tested too."""
+import os
+
+import numpy as np
+import pytest
+
+from denseflow_amd.synth import SynthClip
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("w,h,seed,dt", [(64, 48, 3, 1), (97, 61, 9, 1), (224, 224, 1, 1), (320, 200, 6, 2),
+                                         (20, 33, 2, 1)])
+def test_single_pair_matches_oracle(dfx, oracle, w, h, seed, dt):
+    clip = SynthClip(w, h, seed)
+    f0, f1 = clip.frame(0), clip.frame(dt)
+    ref = oracle.brox_calc(f0, f1)
+    with dfx.FlowEngine(w, h, "brox") as eng:
+        out = eng.calc(f0, f1)
+    assert np.max(np.abs(out - ref)) <= TOL
+
+
+def test_bit_exact_with_oracle(dfx, oracle):
+    clip = SynthClip(224, 224, 1)
+    f0, f1 = clip.frame(0), clip.frame(1)
+    ref = oracle.brox_calc(f0, f1)
+    with dfx.FlowEngine(224, 224, "brox") as eng:
+        out = eng.calc(f0, f1)
+    assert np.array_equal(out, ref), f"max-abs {np.max(np.abs(out - ref))}"
+
+
+def test_golden_vectors_and_zero_motion(dfx):
+    g = np.load(os.path.join(GOLDEN, "brox_golden.npz"))
+    for key in [k[:-5] for k in g.files if k.endswith("_flow")]:
+        w, h, seed, t0, t1 = [int(v) for v in g[key + "_meta"]]
+        clip = SynthClip(w, h, seed)
+        with dfx.FlowEngine(w, h, "brox") as eng:
+            out = eng.calc(clip.frame(t0), clip.frame(t1))
+            zero = eng.calc(clip.frame(t0), clip.frame(t0))
+        assert np.max(np.abs(out - g[key + "_flow"])) <= TOL, key
+        assert np.all(zero == 0.0)
+
+
+def test_flowbuffer_step2_batching_and_parameters(dfx, oracle):
+    """BASELINE config 5 uses -s=2: flow i is frame i -> i+2."""
+    w, h, n = 96, 80, 6
+    frames = SynthClip(w, h, 21).frames(n)
+    with dfx.FlowEngine(w, h, "brox", max_batch=3) as eng:
+        flows = eng.calc_optflows(frames, 2)
+    assert len(flows) == n - 2
+    for i in range(n - 2):
+        assert np.max(np.abs(flows[i] - oracle.brox_calc(frames[i], frames[i + 2]))) <= TOL, i
+    p = oracle.brox_default_params()
+    p.inner_iterations, p.solver_iterations, p.outer_iterations = 3, 4, 5
+    ref = oracle.brox_calc(frames[0], frames[1], p)
+    with dfx.FlowEngine(w, h, "brox", brox_inner_iterations=3, brox_solver_iterations=4,
+                        brox_outer_iterations=5) as eng:
+        out = eng.calc(frames[0], frames[1])
+    assert np.max(np.abs(out - ref)) <= TOL
+
+
+def test_large_pyramid_1080p(dfx, oracle):
+    w, h = 1920, 1080
+    clip = SynthClip(w, h, 5)
+    f0, f1 = clip.frame(0), clip.frame(2)
+    with dfx.FlowEngine(w, h, "brox", max_batch=2) as eng:
+        out = eng.calc(f0, f1)
+        st = eng.stats()
+    assert st.levels == min(len(oracle.brox_pyramid_sizes(w, h)), 16)
+    ref = oracle.brox_calc(f0, f1)
+    assert np.max(np.abs(out - ref)) <= TOL
+    gt = clip.true_flow(0, 2)
+    assert np.abs(out - gt)[64:-64, 64:-64].mean() < 0.05
