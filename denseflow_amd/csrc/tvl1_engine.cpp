@@ -288,7 +288,7 @@ int Tvl1Engine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
             for (int g = 0;; ++g) {
                 for (int i = 0; i < G; ++i)
                     tvl1_launch_step(c->stream, x, step_id++, impl, tile_h);
-                c->stats.kernel_launches += (uint64_t)G * (impl == 1 ? 1 : 2); // warp kernel + iteration kernel per slot
+                c->stats.kernel_launches += G;
                 HIPCHK(c, hipEventRecord(ev_group[g & 1], c->stream));
                 if (g >= 1) { // look at the group before the one just enqueued: the device never idles
                     HIPCHK(c, hipEventSynchronize(ev_group[(g - 1) & 1]));
