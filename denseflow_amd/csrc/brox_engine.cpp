@@ -177,13 +177,21 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
         for (int in = 0; in < p.brox_inner_iterations; ++in) {
             brox_launch_stage1(c->stream, x, uv);
             brox_launch_stage2(c->stream, x);
-            for (int si = 0; si < p.brox_solver_iterations; ++si) {
-                brox_launch_sor(c->stream, x, uv, 0);
-                brox_launch_sor(c->stream, x, uv, 1);
+            if (p.impl == 1) { // simple form: one launch per half sweep
+                for (int si = 0; si < p.brox_solver_iterations; ++si) {
+                    brox_launch_sor(c->stream, x, uv, 0);
+                    brox_launch_sor(c->stream, x, uv, 1);
+                }
+            } else {
+                const int S = brox_fused_sweeps();
+                for (int si = 0; si < p.brox_solver_iterations; si += S)
+                    brox_launch_sor_fused(c->stream, x, uv, std::min(S, p.brox_solver_iterations - si));
             }
         }
         brox_launch_add_increment(c->stream, x, uv);
-        batch_launches += 2 + (uint64_t)p.brox_inner_iterations * (2 + 2 * p.brox_solver_iterations);
+        batch_launches += 2 + (uint64_t)p.brox_inner_iterations *
+                                  (2 + (p.impl == 1 ? 2 * p.brox_solver_iterations
+                                                    : (p.brox_solver_iterations + brox_fused_sweeps() - 1) / brox_fused_sweeps()));
         if (l > 0) {
             brox_launch_prolongate(c->stream, x, uv, lv[l - 1].w, lv[l - 1].h, lv[l - 1].pitch, p.brox_scale_factor,
                                    1.0f / p.brox_scale_factor);

@@ -41,6 +41,9 @@ void brox_launch_level_init(hipStream_t s, const BroxLevelCtx &c, int uv_set, in
 void brox_launch_stage1(hipStream_t s, const BroxLevelCtx &c, int uv_set);
 void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c);
 void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int color);
+// n_sweeps (<= brox_fused_sweeps()) full red+black sweeps in one launch (LDS tile, recomputed halo)
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int n_sweeps);
+int brox_fused_sweeps(void);
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set);
 // (u,v)[uv_set ^ 1] at the finer geometry = bicubic(u,v[uv_set]) * mul
 void brox_launch_prolongate(hipStream_t s, const BroxLevelCtx &c_coarse, int uv_set, int dw, int dh, int dpitch,

@@ -245,6 +245,112 @@ __global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, in
     DV[o] = dv_n;
 }
 
+// Fused SOR: up to BROX_FUSE_SWEEPS full red+black sweeps per launch on a 128 x 32 tile (1024 threads,
+// each owning a 2-column x 2-row patch: 14 values x 4 pixels stay under 128 VGPRs, 16 waves per CU).  The 9 per-pixel coefficients and u, v stay in registers, only
+// w = u + du (the quantity neighbours read) lives in LDS.  Tile origins are even, so a pixel's colour is a
+// compile-time function of its position in the patch.  Every half-sweep shrinks the valid region by one
+// pixel; a halo of 2 pixels per sweep is recomputed redundantly and only the inner region is written
+// back.  Same per-pixel expression, same order: bit-identical to the one-launch-per-half-sweep form.
+#define BROX_FUSE_SWEEPS 2
+#define BROX_TW 128
+#define BROX_TH 32
+#define BROX_HALO (2 * BROX_FUSE_SWEEPS)
+
+#define BROX_PR 2 // patch rows per thread
+__global__ __launch_bounds__(1024) void k_brox_sor_fused(BroxLevelCtx c, int uv_set, int n_sweeps, int tiles_x) {
+    __shared__ float WU[BROX_TH][BROX_TW];
+    __shared__ float WV[BROX_TH][BROX_TW];
+    const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x0 = tx * (BROX_TW - 2 * BROX_HALO) - BROX_HALO; // even
+    const int y0 = ty * (BROX_TH - 2 * BROX_HALO) - BROX_HALO; // even
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx0 = 2 * lane, ly0 = BROX_PR * wave;
+
+    const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
+    float *DU = bplane(c, b, BROX_PL_DU), *DV = bplane(c, b, BROX_PL_DV);
+    const float *GX = bplane(c, b, BROX_PL_GX), *GY = bplane(c, b, BROX_PL_GY);
+    const float *IDU = bplane(c, b, BROX_PL_IDU), *IDV = bplane(c, b, BROX_PL_IDV);
+    const float *NDUDV = bplane(c, b, BROX_PL_NDUDV), *NU = bplane(c, b, BROX_PL_NU), *NV = bplane(c, b, BROX_PL_NV);
+
+    float gl[BROX_PR][2], gr[BROX_PR][2], gd[BROX_PR][2], gu[BROX_PR][2], gs[BROX_PR][2], idu[BROX_PR][2], idv[BROX_PR][2], nd[BROX_PR][2], nu[BROX_PR][2], nv[BROX_PR][2];
+    float uu[BROX_PR][2], vv[BROX_PR][2], du[BROX_PR][2], dv[BROX_PR][2];
+#pragma unroll
+    for (int i = 0; i < BROX_PR; ++i) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int x = x0 + lx0 + k, y = y0 + ly0 + i;
+            const bool in = x >= 0 && x < w && y >= 0 && y < h;
+            const long long o = in ? ((long long)y * pitch + x) : 0;
+            gl[i][k] = in ? GX[o] : 0.0f;
+            gr[i][k] = (in && x + 1 < w) ? GX[o + 1] : 0.0f;
+            gd[i][k] = in ? GY[o] : 0.0f;
+            gu[i][k] = (in && y + 1 < h) ? GY[o + pitch] : 0.0f;
+            gs[i][k] = ((gl[i][k] + gr[i][k]) + gd[i][k]) + gu[i][k];
+            idu[i][k] = in ? IDU[o] : 0.0f;
+            idv[i][k] = in ? IDV[o] : 0.0f;
+            nd[i][k] = in ? NDUDV[o] : 0.0f;
+            nu[i][k] = in ? NU[o] : 0.0f;
+            nv[i][k] = in ? NV[o] : 0.0f;
+            uu[i][k] = in ? u[o] : 0.0f;
+            vv[i][k] = in ? v[o] : 0.0f;
+            du[i][k] = in ? DU[o] : 0.0f;
+            dv[i][k] = in ? DV[o] : 0.0f;
+            WU[ly0 + i][lx0 + k] = uu[i][k] + du[i][k];
+            WV[ly0 + i][lx0 + k] = vv[i][k] + dv[i][k];
+        }
+    }
+    __syncthreads();
+    const float omega = c.omega;
+    for (int sw = 0; sw < n_sweeps; ++sw) {
+#pragma unroll
+        for (int color = 0; color < 2; ++color) {
+#pragma unroll
+            for (int i = 0; i < BROX_PR; ++i) {
+                // (x + y) parity of patch element (i, k) is (i + k) & 1 because x0, y0, lx0, ly0 are even
+                const int k = (i + color) & 1;
+                const int lx = lx0 + k, ly = ly0 + i;
+                const int lxl = max(lx - 1, 0), lxr = min(lx + 1, BROX_TW - 1);
+                const int lyd = max(ly - 1, 0), lyu = min(ly + 1, BROX_TH - 1);
+                const float su = (((gl[i][k] * WU[ly][lxl] + gr[i][k] * WU[ly][lxr]) + gd[i][k] * WU[lyd][lx]) +
+                                  gu[i][k] * WU[lyu][lx]) -
+                                 gs[i][k] * uu[i][k];
+                const float sv = (((gl[i][k] * WV[ly][lxl] + gr[i][k] * WV[ly][lxr]) + gd[i][k] * WV[lyd][lx]) +
+                                  gu[i][k] * WV[lyu][lx]) -
+                                 gs[i][k] * vv[i][k];
+                const float du_n =
+                    (1.0f - omega) * du[i][k] + omega * (idu[i][k] * ((su - nu[i][k]) - nd[i][k] * dv[i][k]));
+                const float dv_n =
+                    (1.0f - omega) * dv[i][k] + omega * (idv[i][k] * ((sv - nv[i][k]) - nd[i][k] * du_n));
+                du[i][k] = du_n;
+                dv[i][k] = dv_n;
+            }
+            __syncthreads(); // every read of the old w of this colour's neighbours is done
+#pragma unroll
+            for (int i = 0; i < BROX_PR; ++i) {
+                const int k = (i + color) & 1;
+                WU[ly0 + i][lx0 + k] = uu[i][k] + du[i][k];
+                WV[ly0 + i][lx0 + k] = vv[i][k] + dv[i][k];
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < BROX_PR; ++i) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int lx = lx0 + k, ly = ly0 + i;
+            const int x = x0 + lx, y = y0 + ly;
+            if (lx >= BROX_HALO && lx < BROX_TW - BROX_HALO && ly >= BROX_HALO && ly < BROX_TH - BROX_HALO && x < w &&
+                y < h) {
+                const long long o = (long long)y * pitch + x;
+                DU[o] = du[i][k];
+                DV[o] = dv[i][k];
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int uv_set) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -328,6 +434,13 @@ void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c) {
 void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int color) {
     hipLaunchKernelGGL(k_brox_sor, bgrid((c.w + 1) / 2, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, color);
 }
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int n_sweeps) {
+    const int tiles_x = (c.w + (BROX_TW - 2 * BROX_HALO) - 1) / (BROX_TW - 2 * BROX_HALO);
+    const int tiles_y = (c.h + (BROX_TH - 2 * BROX_HALO) - 1) / (BROX_TH - 2 * BROX_HALO);
+    hipLaunchKernelGGL(k_brox_sor_fused, dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(1024), 0, s, c, uv_set, n_sweeps,
+                       tiles_x);
+}
+int brox_fused_sweeps(void) { return BROX_FUSE_SWEEPS; }
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set) {
     hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set);
 }

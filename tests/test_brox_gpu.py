@@ -76,3 +76,17 @@ def test_large_pyramid_1080p(dfx, oracle):
     assert np.max(np.abs(out - ref)) <= TOL
     gt = clip.true_flow(0, 2)
     assert np.abs(out - gt)[64:-64, 64:-64].mean() < 0.05
+
+
+def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
+    """The fused SOR kernel (LDS tile, recomputed halo, several sweeps per launch) must not change a bit
+    relative to the simple form, for even and odd solver-iteration counts."""
+    w, h = 300, 170
+    clip = SynthClip(w, h, 8)
+    f0, f1 = clip.frame(0), clip.frame(1)
+    for solver in (10, 3):
+        with dfx.FlowEngine(w, h, "brox", impl=1, brox_solver_iterations=solver) as eng:
+            simple = eng.calc(f0, f1)
+        with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver) as eng:
+            fused = eng.calc(f0, f1)
+        assert np.array_equal(simple, fused), solver
