@@ -174,21 +174,24 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
     for (int l = (int)lv.size() - 1; l >= 0; --l) {
         const BroxLevelCtx x = level_ctx(l, nb);
         brox_launch_level_init(c->stream, x, uv, l == (int)lv.size() - 1);
+        int ds = 0; // du/dv set holding the current increment
         for (int in = 0; in < p.brox_inner_iterations; ++in) {
-            brox_launch_stage1(c->stream, x, uv);
+            brox_launch_stage1(c->stream, x, uv, ds);
             brox_launch_stage2(c->stream, x);
-            if (p.impl == 1) { // simple form: one launch per half sweep
+            if (p.impl == 1) { // simple form: one launch per half sweep, in place
                 for (int si = 0; si < p.brox_solver_iterations; ++si) {
-                    brox_launch_sor(c->stream, x, uv, 0);
-                    brox_launch_sor(c->stream, x, uv, 1);
+                    brox_launch_sor(c->stream, x, uv, ds, 0);
+                    brox_launch_sor(c->stream, x, uv, ds, 1);
                 }
             } else {
                 const int S = brox_fused_sweeps();
-                for (int si = 0; si < p.brox_solver_iterations; si += S)
-                    brox_launch_sor_fused(c->stream, x, uv, std::min(S, p.brox_solver_iterations - si));
+                for (int si = 0; si < p.brox_solver_iterations; si += S) {
+                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si));
+                    ds ^= 1; // it wrote the other set
+                }
             }
         }
-        brox_launch_add_increment(c->stream, x, uv);
+        brox_launch_add_increment(c->stream, x, uv, ds);
         batch_launches += 2 + (uint64_t)p.brox_inner_iterations *
                                   (2 + (p.impl == 1 ? 2 * p.brox_solver_iterations
                                                     : (p.brox_solver_iterations + brox_fused_sweeps() - 1) / brox_fused_sweeps()));

@@ -12,7 +12,9 @@
 #include "dfx_device.h"
 
 enum : int { BROX_PL_U0 = 0, BROX_PL_V0, BROX_PL_U1, BROX_PL_V1, BROX_PL_DU, BROX_PL_DV, BROX_PL_GX, BROX_PL_GY,
-             BROX_PL_IDU, BROX_PL_IDV, BROX_PL_NDUDV, BROX_PL_NU, BROX_PL_NV, BROX_PL_COUNT };
+             BROX_PL_IDU, BROX_PL_IDV, BROX_PL_NDUDV, BROX_PL_NU, BROX_PL_NV, BROX_PL_DU1, BROX_PL_DV1, BROX_PL_COUNT };
+// du/dv exist twice (DU/DV = set 0, DU1/DV1 = set 1): the fused SOR kernel reads one set (with halo) and
+// writes the other, because neighbouring workgroups of the same launch read each other's pixels.
 enum : int { BROX_FP_I = 0, BROX_FP_DX, BROX_FP_DY, BROX_FP_DXX, BROX_FP_DXY, BROX_FP_DYY, BROX_FP_COUNT };
 
 struct BroxLevelCtx {
@@ -37,14 +39,14 @@ void brox_launch_downsample(hipStream_t s, float *frames, long long frame_stride
 // dst plane = D_axis(src plane) for one level (axis 0 = x, 1 = y)
 void brox_launch_deriv(hipStream_t s, float *frames, long long frame_stride, const int *frame_slots, int n_frames,
                        long long src_off, long long dst_off, int w, int h, int pitch, int axis);
-void brox_launch_level_init(hipStream_t s, const BroxLevelCtx &c, int uv_set, int zero_uv);
-void brox_launch_stage1(hipStream_t s, const BroxLevelCtx &c, int uv_set);
+void brox_launch_level_init(hipStream_t s, const BroxLevelCtx &c, int uv_set, int zero_uv); // zeroes du/dv set 0
+void brox_launch_stage1(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set);
 void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c);
-void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int color);
+void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set, int color); // in place
 // n_sweeps (<= brox_fused_sweeps()) full red+black sweeps in one launch (LDS tile, recomputed halo)
-void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int n_sweeps);
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps); // writes set d_src^1
 int brox_fused_sweeps(void);
-void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set);
+void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set);
 // (u,v)[uv_set ^ 1] at the finer geometry = bicubic(u,v[uv_set]) * mul
 void brox_launch_prolongate(hipStream_t s, const BroxLevelCtx &c_coarse, int uv_set, int dw, int dh, int dpitch,
                             float factor, float mul);

@@ -32,6 +32,8 @@ __device__ __forceinline__ float brox_bicubic_w(float x_) {
 __device__ __forceinline__ float *bplane(const BroxLevelCtx &c, int pair, int plane) {
     return c.planes + (long long)pair * c.slot_stride + (long long)plane * c.plane_stride;
 }
+__device__ __forceinline__ int du_plane(int d_set) { return d_set ? BROX_PL_DU1 : BROX_PL_DU; }
+__device__ __forceinline__ int dv_plane(int d_set) { return d_set ? BROX_PL_DV1 : BROX_PL_DV; }
 __device__ __forceinline__ const float *fplane(const BroxLevelCtx &c, int slot, int plane) {
     return c.frames + (long long)slot * c.frame_stride + (long long)plane * c.pyr_elems + c.lvl_off;
 }
@@ -141,7 +143,7 @@ __device__ __forceinline__ float bl_sample(const float *p, const BlTap &t) {
 }
 
 // stage 1: data-term coefficients and staggered diffusivities (brox_oracle.h, step 3b)
-__global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set) {
+__global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set, int d_set) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= c.w || y >= c.h)
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set)
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
     const PairDesc pd = c.pairs[b];
     const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
-    const float *DU = bplane(c, b, BROX_PL_DU), *DV = bplane(c, b, BROX_PL_DV);
+    const float *DU = bplane(c, b, du_plane(d_set)), *DV = bplane(c, b, dv_plane(d_set));
     const long long o = (long long)y * pitch + x;
     const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
 #define WU(xx, yy) (u[(long long)(yy)*pitch + (xx)] + DU[(long long)(yy)*pitch + (xx)])
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void k_brox_stage2(BroxLevelCtx c) {
 
 // one red/black SOR half-sweep: only pixels with (x + y) % 2 == color are updated (in place; their four
 // neighbours have the other colour and are not touched by this launch)
-__global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, int color) {
+__global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, int d_set, int color) {
     const int xh = blockIdx.x * 64 + (threadIdx.x & 63); // half-resolution column index
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (y >= c.h)
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, in
         return;
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
     const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
-    float *DU = bplane(c, b, BROX_PL_DU), *DV = bplane(c, b, BROX_PL_DV);
+    float *DU = bplane(c, b, du_plane(d_set)), *DV = bplane(c, b, dv_plane(d_set));
     const float *GX = bplane(c, b, BROX_PL_GX), *GY = bplane(c, b, BROX_PL_GY);
     const long long o = (long long)y * pitch + x;
     const long long ol = (long long)y * pitch + max(x - 1, 0), orr = (long long)y * pitch + min(x + 1, w - 1);
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, in
 #define BROX_HALO (2 * BROX_FUSE_SWEEPS)
 
 #define BROX_PR 2 // patch rows per thread
-__global__ __launch_bounds__(1024) void k_brox_sor_fused(BroxLevelCtx c, int uv_set, int n_sweeps, int tiles_x) {
+__global__ __launch_bounds__(1024) void k_brox_sor_fused(BroxLevelCtx c, int uv_set, int d_src, int n_sweeps, int tiles_x) {
     __shared__ float WU[BROX_TH][BROX_TW];
     __shared__ float WV[BROX_TH][BROX_TW];
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
@@ -268,7 +270,8 @@ __global__ __launch_bounds__(1024) void k_brox_sor_fused(BroxLevelCtx c, int uv_
     const int lx0 = 2 * lane, ly0 = BROX_PR * wave;
 
     const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
-    float *DU = bplane(c, b, BROX_PL_DU), *DV = bplane(c, b, BROX_PL_DV);
+    const float *DU = bplane(c, b, du_plane(d_src)), *DV = bplane(c, b, dv_plane(d_src));
+    float *DUo = bplane(c, b, du_plane(d_src ^ 1)), *DVo = bplane(c, b, dv_plane(d_src ^ 1));
     const float *GX = bplane(c, b, BROX_PL_GX), *GY = bplane(c, b, BROX_PL_GY);
     const float *IDU = bplane(c, b, BROX_PL_IDU), *IDV = bplane(c, b, BROX_PL_IDV);
     const float *NDUDV = bplane(c, b, BROX_PL_NDUDV), *NU = bplane(c, b, BROX_PL_NU), *NV = bplane(c, b, BROX_PL_NV);
@@ -344,14 +347,14 @@ __global__ __launch_bounds__(1024) void k_brox_sor_fused(BroxLevelCtx c, int uv_
             if (lx >= BROX_HALO && lx < BROX_TW - BROX_HALO && ly >= BROX_HALO && ly < BROX_TH - BROX_HALO && x < w &&
                 y < h) {
                 const long long o = (long long)y * pitch + x;
-                DU[o] = du[i][k];
-                DV[o] = dv[i][k];
+                DUo[o] = du[i][k];
+                DVo[o] = dv[i][k];
             }
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int uv_set) {
+__global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int uv_set, int d_set) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= c.w || y >= c.h)
@@ -359,8 +362,8 @@ __global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int 
     const int b = blockIdx.z;
     const long long o = (long long)y * c.pitch + x;
     float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
-    u[o] = u[o] + bplane(c, b, BROX_PL_DU)[o];
-    v[o] = v[o] + bplane(c, b, BROX_PL_DV)[o];
+    u[o] = u[o] + bplane(c, b, du_plane(d_set))[o];
+    v[o] = v[o] + bplane(c, b, dv_plane(d_set))[o];
 }
 
 __global__ __launch_bounds__(256) void k_brox_prolongate(BroxLevelCtx c, int uv_set, int dw, int dh, int dpitch,
@@ -425,24 +428,24 @@ void brox_launch_deriv(hipStream_t s, float *frames, long long frame_stride, con
 void brox_launch_level_init(hipStream_t s, const BroxLevelCtx &c, int uv_set, int zero_uv) {
     hipLaunchKernelGGL(k_brox_level_init, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, zero_uv);
 }
-void brox_launch_stage1(hipStream_t s, const BroxLevelCtx &c, int uv_set) {
-    hipLaunchKernelGGL(k_brox_stage1, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set);
+void brox_launch_stage1(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set) {
+    hipLaunchKernelGGL(k_brox_stage1, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set);
 }
 void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c) {
     hipLaunchKernelGGL(k_brox_stage2, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c);
 }
-void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int color) {
-    hipLaunchKernelGGL(k_brox_sor, bgrid((c.w + 1) / 2, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, color);
+void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set, int color) {
+    hipLaunchKernelGGL(k_brox_sor, bgrid((c.w + 1) / 2, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set, color);
 }
-void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int n_sweeps) {
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps) {
     const int tiles_x = (c.w + (BROX_TW - 2 * BROX_HALO) - 1) / (BROX_TW - 2 * BROX_HALO);
     const int tiles_y = (c.h + (BROX_TH - 2 * BROX_HALO) - 1) / (BROX_TH - 2 * BROX_HALO);
-    hipLaunchKernelGGL(k_brox_sor_fused, dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(1024), 0, s, c, uv_set, n_sweeps,
+    hipLaunchKernelGGL(k_brox_sor_fused, dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(1024), 0, s, c, uv_set, d_src, n_sweeps,
                        tiles_x);
 }
 int brox_fused_sweeps(void) { return BROX_FUSE_SWEEPS; }
-void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set) {
-    hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set);
+void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set) {
+    hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set);
 }
 void brox_launch_prolongate(hipStream_t s, const BroxLevelCtx &c, int uv_set, int dw, int dh, int dpitch, float factor,
                             float mul) {

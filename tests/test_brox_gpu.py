@@ -81,7 +81,9 @@ def test_large_pyramid_1080p(dfx, oracle):
 def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
     """The fused SOR kernel (LDS tile, recomputed halo, several sweeps per launch) must not change a bit
     relative to the simple form, for even and odd solver-iteration counts."""
-    w, h = 300, 170
+    # large enough that workgroups of one launch are NOT all co-resident: an in-place update of du/dv would
+    # race with neighbours reading their halo (this caught exactly that bug; the kernel ping-pongs two sets)
+    w, h = 1000, 600
     clip = SynthClip(w, h, 8)
     f0, f1 = clip.frame(0), clip.frame(1)
     for solver in (10, 3):
