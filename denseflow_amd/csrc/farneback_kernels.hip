@@ -200,6 +200,9 @@ __global__ __launch_bounds__(256) void k_farn_init_flow(FarnPairCtx c, int cur_s
 
 __constant__ float c_farn_border[6] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f, 1.f};
 
+// 8-byte load with 4-byte alignment: the two horizontal taps of a bilinear sample
+typedef float float2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
 // B.7 for one pixel.  R0/R1 point at plane 0 of the level inside the two frame slots.
 __device__ __forceinline__ void update_matrices_px(const float *R0, const float *R1, int w, int h, int pitch, int x,
                                                    int y, float dx, float dy, float (&M)[5]) {
@@ -222,7 +225,9 @@ __device__ __forceinline__ void update_matrices_px(const float *R0, const float 
 #pragma unroll
         for (int p = 0; p < 5; ++p) {
             const float *Rp = R1 + p * ps;
-            v[p] = ((a00 * Rp[q] + a01 * Rp[q + 1]) + a10 * Rp[q + pitch]) + a11 * Rp[q + pitch + 1];
+            const float2_a4 t0 = *reinterpret_cast<const float2_a4 *>(Rp + q);
+            const float2_a4 t1 = *reinterpret_cast<const float2_a4 *>(Rp + q + pitch);
+            v[p] = ((a00 * t0[0] + a01 * t0[1]) + a10 * t1[0]) + a11 * t1[1];
         }
         r2 = v[0];
         r3 = v[1];
