@@ -301,6 +301,7 @@ int dfx_get_stats(dfx_handle h, dfx_stats *out) {
     if (!h || !out)
         return DFX_ERR_INVALID;
     *out = h->stats;
+    out->batch = h->engine ? h->engine->batch() : 0;
     return DFX_OK;
 }
 

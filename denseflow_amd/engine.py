@@ -66,6 +66,7 @@ class DfxParams(C.Structure):
 class DfxStats(C.Structure):
     _fields_ = [
         ("pairs", C.c_uint64),
+        ("batch", C.c_int),
         ("kernel_launches", C.c_uint64),
         ("noop_steps", C.c_uint64),
         ("device_ms", C.c_double),
