@@ -49,23 +49,36 @@ void default_params(dfx_params *p) {
 
 int ensure_staging(dfx_context *c, int u8_need, int flow_need) {
     if (u8_need > c->u8_slots) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        dfx_free_dev(c->d_u8);
-        HIPCHK(c, hipMalloc(&c->d_u8, (size_t)u8_need * c->W * c->H));
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto &p : c->d_u8) {
+            dfx_free_dev(p);
+            HIPCHK(c, hipMalloc(&p, (size_t)u8_need * c->W * c->H));
+        }
         c->u8_slots = u8_need;
     }
     if (flow_need > c->flow_slots) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        dfx_free_dev(c->d_flow_out);
-        HIPCHK(c, hipMalloc(&c->d_flow_out, (size_t)flow_need * c->W * c->H * 2 * sizeof(float)));
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto &p : c->d_flow_out) {
+            dfx_free_dev(p);
+            HIPCHK(c, hipMalloc(&p, (size_t)flow_need * c->W * c->H * 2 * sizeof(float)));
+        }
         c->flow_slots = flow_need;
     }
     return DFX_OK;
 }
 
+struct BatchPlan {
+    int i0, nb;          // pairs [i0, i0+nb)
+    long long first_new; // first frame id that has to be prepared for this batch
+    int n_new;           // number of such frames
+};
+
 // Shared driver for host- and device-resident frames.
-//   host mode  : frames[i] host pointers (frame_pitch), flows[i] host pointers (out_pitch bytes)
-//   device mode: d_frames / d_flows contiguous device arrays
+//   host mode  : frames[i] host pointers (frame_pitch), flows[i] host pointers (out_pitch bytes).
+//                Copies run on their own stream through two staging sets: the frames of batch i+1 go up
+//                and the flows of batch i-1 come down while batch i computes (the reference uploads,
+//                computes and downloads one pair at a time with a blocking download, :317-339).
+//   device mode: d_frames / d_flows contiguous device arrays, no copies at all.
 int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_pitch, const uint8_t *d_frames,
                     size_t d_pitch, size_t d_frame_stride, int n_frames, int step, float *const *flows,
                     size_t out_pitch, float *d_flows, size_t d_flow_stride) {
@@ -88,61 +101,111 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             return rc;
     }
     const int F = E->frame_slots();
-    c->frames_built = 0;
     c->h_slots.resize(F);
     c->h_pairs.resize(B);
 
-    for (int i0 = 0; i0 < M; i0 += B) {
-        const int nb = std::min(B, M - i0);
-        HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
-        // frames [i0, i0+nb+astep) must be resident; ids below frames_built already are.
-        // Frame id f lives in slot f % F; F >= nb + astep, so a batch never evicts what it needs.
-        const long long need_end = (long long)i0 + nb + astep;
-        const long long first_new = std::max<long long>(c->frames_built, i0);
-        const int n_new = (int)(need_end - first_new);
-        for (int k = 0; k < n_new; ++k)
-            c->h_slots[k] = (int)((first_new + k) % F);
-        if (n_new > 0) {
-            if (host_mode) {
-                for (int k = 0; k < n_new; ++k)
-                    HIPCHK(c, hipMemcpy2DAsync(c->d_u8 + (size_t)k * c->W * c->H, c->W, frames[first_new + k],
-                                               frame_pitch, c->W, c->H, hipMemcpyHostToDevice, c->stream));
-                rc = E->build_frames(c->d_u8, (long long)c->W * c->H, c->W, n_new, c->h_slots.data());
-            } else {
-                rc = E->build_frames(d_frames + (size_t)first_new * d_frame_stride, (long long)d_frame_stride,
-                                     (long long)d_pitch, n_new, c->h_slots.data());
+    // Frames [i0, i0+nb+astep) must be resident for a batch; earlier batches already prepared the ids below
+    // their own end.  Frame id f lives in slot f % F; F >= nb + astep, so a batch never evicts what it needs.
+    std::vector<BatchPlan> plan;
+    {
+        long long built = 0;
+        for (int i0 = 0; i0 < M; i0 += B) {
+            BatchPlan p;
+            p.i0 = i0;
+            p.nb = std::min(B, M - i0);
+            const long long need_end = (long long)i0 + p.nb + astep;
+            p.first_new = std::max<long long>(built, i0);
+            p.n_new = (int)std::max<long long>(need_end - p.first_new, 0);
+            built = std::max(built, need_end);
+            plan.push_back(p);
+        }
+    }
+    auto upload = [&](size_t k) -> int { // host frames of batch k -> staging set k&1 (copy stream)
+        const BatchPlan &p = plan[k];
+        unsigned char *dst = c->d_u8[k & 1];
+        for (int j = 0; j < p.n_new; ++j)
+            HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)j * c->W * c->H, c->W, frames[p.first_new + j], frame_pitch, c->W,
+                                       c->H, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev_h2d[k & 1], c->copy_stream));
+        return DFX_OK;
+    };
+    auto download = [&](size_t k) -> int { // flows of batch k: staging set k&1 -> host (copy stream)
+        const BatchPlan &p = plan[k];
+        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute[k & 1], 0));
+        for (int j = 0; j < p.nb; ++j)
+            HIPCHK(c, hipMemcpy2DAsync(flows[p.i0 + j], out_pitch, c->d_flow_out[k & 1] + (size_t)j * c->W * c->H * 2,
+                                       (size_t)c->W * 8, (size_t)c->W * 8, c->H, hipMemcpyDeviceToHost,
+                                       c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev_d2h[k & 1], c->copy_stream));
+        return DFX_OK;
+    };
+
+    if (host_mode) {
+        rc = upload(0);
+        if (rc != DFX_OK)
+            return rc;
+    }
+    for (size_t k = 0; k < plan.size(); ++k) {
+        const BatchPlan &p = plan[k];
+        if (host_mode) {
+            // copy stream, in order: flows of batch k-1 down (after its compute), frames of batch k+1 up.
+            // Staging set (k+1)&1 was last read by batch k-1's frame preparation, which the download just
+            // enqueued already waits for.
+            if (k >= 1) {
+                rc = download(k - 1);
+                if (rc != DFX_OK)
+                    return rc;
             }
+            if (k + 1 < plan.size()) {
+                rc = upload(k + 1);
+                if (rc != DFX_OK)
+                    return rc;
+            }
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d[k & 1], 0));
+            if (k >= 2) // flow staging set k&1 must have been drained by the download of batch k-2
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2h[k & 1], 0));
+        }
+        HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
+        for (int j = 0; j < p.n_new; ++j)
+            c->h_slots[j] = (int)((p.first_new + j) % F);
+        if (p.n_new > 0) {
+            if (host_mode)
+                rc = E->build_frames(c->d_u8[k & 1], (long long)c->W * c->H, c->W, p.n_new, c->h_slots.data());
+            else
+                rc = E->build_frames(d_frames + (size_t)p.first_new * d_frame_stride, (long long)d_frame_stride,
+                                     (long long)d_pitch, p.n_new, c->h_slots.data());
             if (rc != DFX_OK)
                 return rc;
-            c->frames_built = need_end;
         }
         // pair i: a = (step>0 ? i : i-step), b = (step>0 ? i+step : i)   (src/denseflow_gpu.cpp:315-316)
-        for (int k = 0; k < nb; ++k) {
-            const int i = i0 + k;
+        for (int j = 0; j < p.nb; ++j) {
+            const int i = p.i0 + j;
             const int a = step > 0 ? i : i - step;
             const int b = step > 0 ? i + step : i;
-            c->h_pairs[k].frame_a = a % F;
-            c->h_pairs[k].frame_b = b % F;
+            c->h_pairs[j].frame_a = a % F;
+            c->h_pairs[j].frame_b = b % F;
         }
-        float *dst = host_mode ? c->d_flow_out : d_flows + (size_t)i0 * d_flow_stride;
+        float *dst = host_mode ? c->d_flow_out[k & 1] : d_flows + (size_t)p.i0 * d_flow_stride;
         const long long dst_stride = host_mode ? (long long)c->W * c->H * 2 : (long long)d_flow_stride;
-        rc = E->run_pairs(nb, c->h_pairs.data(), dst, dst_stride);
+        rc = E->run_pairs(p.nb, c->h_pairs.data(), dst, dst_stride);
         if (rc != DFX_OK)
             return rc;
         HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
-        if (host_mode) {
-            for (int k = 0; k < nb; ++k)
-                HIPCHK(c, hipMemcpy2DAsync(flows[i0 + k], out_pitch, c->d_flow_out + (size_t)k * c->W * c->H * 2,
-                                           (size_t)c->W * 8, (size_t)c->W * 8, c->H, hipMemcpyDeviceToHost,
-                                           c->stream));
-        }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (host_mode)
+            HIPCHK(c, hipEventRecord(c->ev_compute[k & 1], c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream)); // the engines' statistics read-backs are complete
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
         c->stats.device_ms += ms;
-        rc = E->account(nb);
+        rc = E->account(p.nb);
         if (rc != DFX_OK)
             return rc;
+    }
+    if (host_mode) {
+        rc = download(plan.size() - 1);
+        if (rc != DFX_OK)
+            return rc;
+        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     }
     return DFX_OK;
 }
@@ -228,6 +291,13 @@ int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height
     auto init = [&]() -> int {
         HIPCHK(c, hipSetDevice(device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (auto &e : c->ev_h2d)
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_compute)
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_d2h)
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(c, hipEventCreate(&c->ev_t0));
         HIPCHK(c, hipEventCreate(&c->ev_t1));
         if (algo == DFX_ALGO_TVL1)
@@ -320,8 +390,23 @@ void dfx_destroy(dfx_handle h) {
         (void)hipStreamSynchronize(h->stream);
     delete h->engine;
     h->engine = nullptr;
-    dfx_free_dev(h->d_u8);
-    dfx_free_dev(h->d_flow_out);
+    if (h->copy_stream)
+        (void)hipStreamSynchronize(h->copy_stream);
+    for (auto &p : h->d_u8)
+        dfx_free_dev(p);
+    for (auto &p : h->d_flow_out)
+        dfx_free_dev(p);
+    for (auto &e : h->ev_h2d)
+        if (e)
+            (void)hipEventDestroy(e);
+    for (auto &e : h->ev_compute)
+        if (e)
+            (void)hipEventDestroy(e);
+    for (auto &e : h->ev_d2h)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (h->copy_stream)
+        (void)hipStreamDestroy(h->copy_stream);
     if (h->ev_t0)
         (void)hipEventDestroy(h->ev_t0);
     if (h->ev_t1)

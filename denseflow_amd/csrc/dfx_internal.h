@@ -40,19 +40,23 @@ struct dfx_context {
     dfx_params prm{};
     std::string err;
 
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // compute
+    hipStream_t copy_stream = nullptr; // host <-> device copies of the host-pointer entry points
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};     // frames of batch i are in staging set i&1
+    hipEvent_t ev_compute[2] = {nullptr, nullptr}; // flows of batch i are in staging set i&1
+    hipEvent_t ev_d2h[2] = {nullptr, nullptr};     // flow staging set i&1 has been copied out
 
     AlgoEngine *engine = nullptr;
 
     // staging shared by every engine
-    unsigned char *d_u8 = nullptr; // host-mode staging: u8_slots dense W*H frames
+    // host-mode staging, two sets each so that copies of batch i+-1 overlap the compute of batch i
+    unsigned char *d_u8[2] = {nullptr, nullptr}; // u8_slots dense W*H frames per set
     int u8_slots = 0;
-    float *d_flow_out = nullptr;   // host-mode staging: flow_slots dense H*W*2 flows
+    float *d_flow_out[2] = {nullptr, nullptr};   // flow_slots dense H*W*2 flows per set
     int flow_slots = 0;
     std::vector<int> h_slots;      // slot id of each new frame of the current batch
     std::vector<PairDesc> h_pairs; // descriptors of the current batch
-    long long frames_built = 0;    // frame ids [0, frames_built) of the current call are resident
 
     dfx_stats stats{};
 };
