@@ -32,7 +32,7 @@ struct Tvl1State {
     int seg_n0;       // inner-iteration index executed first in the current segment
     int next_check;   // iteration index whose estimateU evaluates the error (TVL1_NO_CHECK: none left)
     int n_checks;     // statistics: convergence sums evaluated at this level
-    int steps_used;   // statistics: steps that did work at this level
+    int pad0_;
     double prev_error;
     double thr;       // scaledEpsilon = eps^2 * W*H of the level
     int iters[TVL1_MAX_WARPS]; // statistics: inner iterations executed per warp at this level
