@@ -133,7 +133,7 @@ def load_library():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for the library itself
         pass
-    L = C.CDLL(_LIB)
+    L = C.CDLL(os.environ.get("DFX_LIBRARY", _LIB))  # DFX_LIBRARY: A/B a differently built libdfx.so
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     L.dfx_device_count.restype = i
     L.dfx_default_params.argtypes = [C.POINTER(DfxParams)]
