@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "dfx_internal.h"
+#include "quantize_kernels.h"
 
 namespace {
 
@@ -47,6 +48,18 @@ void default_params(dfx_params *p) {
     p->brox_solver_iterations = 10;
 }
 
+int ensure_img_staging(dfx_context *c, int img_need) {
+    if (img_need > c->img_slots) {
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto &p : c->d_img) {
+            dfx_free_dev(p);
+            HIPCHK(c, hipMalloc(&p, (size_t)img_need * 2 * c->W * c->H)); // img_need x planes, then the y planes
+        }
+        c->img_slots = img_need;
+    }
+    return DFX_OK;
+}
+
 int ensure_staging(dfx_context *c, int u8_need, int flow_need) {
     if (u8_need > c->u8_slots) {
         HIPCHK(c, hipDeviceSynchronize());
@@ -67,6 +80,22 @@ int ensure_staging(dfx_context *c, int u8_need, int flow_need) {
     return DFX_OK;
 }
 
+// Where the flows of a FlowBuffer go: float (u, v) fields or planes bounded to 8 bits on the device.
+struct OutSpec {
+    bool quantized = false;
+    double lo = 0, hi = 0;
+    // float output
+    float *const *flows = nullptr; // host mode: one pointer per flow, out_pitch bytes per row
+    size_t out_pitch = 0;
+    float *d_flows = nullptr; // device mode: flow i dense at d_flows + i*d_flow_stride
+    size_t d_flow_stride = 0;
+    // 8-bit output
+    uint8_t *const *img_x = nullptr, *const *img_y = nullptr; // host mode: one pointer per plane
+    size_t img_pitch = 0;                                     // bytes per row (host and device mode)
+    uint8_t *d_img_x = nullptr, *d_img_y = nullptr;           // device mode: plane i at + i*d_img_stride
+    size_t d_img_stride = 0;
+};
+
 struct BatchPlan {
     int i0, nb;          // pairs [i0, i0+nb)
     long long first_new; // first frame id that has to be prepared for this batch
@@ -80,8 +109,7 @@ struct BatchPlan {
 //                computes and downloads one pair at a time with a blocking download, :317-339).
 //   device mode: d_frames / d_flows contiguous device arrays, no copies at all.
 int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_pitch, const uint8_t *d_frames,
-                    size_t d_pitch, size_t d_frame_stride, int n_frames, int step, float *const *flows,
-                    size_t out_pitch, float *d_flows, size_t d_flow_stride) {
+                    size_t d_pitch, size_t d_frame_stride, int n_frames, int step, const OutSpec &out) {
     if (n_frames < 0 || step == 0)
         return dfx_fail(c, DFX_ERR_INVALID, "n_frames must be >= 0 and step non-zero");
     const int astep = std::abs(step);
@@ -95,11 +123,17 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     if (rc != DFX_OK)
         return rc;
     const bool host_mode = frames != nullptr;
-    if (host_mode) {
-        rc = ensure_staging(c, B + astep, B);
+    // float flows land in the caller's device array, or in a staging set when they are copied to the host
+    // or only feed the bounding kernel
+    rc = ensure_staging(c, host_mode ? B + astep : 0, (host_mode || out.quantized) ? B : 0);
+    if (rc != DFX_OK)
+        return rc;
+    if (out.quantized && host_mode) {
+        rc = ensure_img_staging(c, B);
         if (rc != DFX_OK)
             return rc;
     }
+    const size_t plane = (size_t)c->W * c->H;
     const int F = E->frame_slots();
     c->h_slots.resize(F);
     c->h_pairs.resize(B);
@@ -132,10 +166,20 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     auto download = [&](size_t k) -> int { // flows of batch k: staging set k&1 -> host (copy stream)
         const BatchPlan &p = plan[k];
         HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute[k & 1], 0));
-        for (int j = 0; j < p.nb; ++j)
-            HIPCHK(c, hipMemcpy2DAsync(flows[p.i0 + j], out_pitch, c->d_flow_out[k & 1] + (size_t)j * c->W * c->H * 2,
-                                       (size_t)c->W * 8, (size_t)c->W * 8, c->H, hipMemcpyDeviceToHost,
-                                       c->copy_stream));
+        for (int j = 0; j < p.nb; ++j) {
+            if (out.quantized) {
+                const unsigned char *sx = c->d_img[k & 1] + (size_t)j * plane;
+                const unsigned char *sy = c->d_img[k & 1] + ((size_t)c->img_slots + j) * plane;
+                HIPCHK(c, hipMemcpy2DAsync(out.img_x[p.i0 + j], out.img_pitch, sx, c->W, c->W, c->H,
+                                           hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, hipMemcpy2DAsync(out.img_y[p.i0 + j], out.img_pitch, sy, c->W, c->W, c->H,
+                                           hipMemcpyDeviceToHost, c->copy_stream));
+            } else {
+                HIPCHK(c, hipMemcpy2DAsync(out.flows[p.i0 + j], out.out_pitch, c->d_flow_out[k & 1] + (size_t)j * plane * 2,
+                                           (size_t)c->W * 8, (size_t)c->W * 8, c->H, hipMemcpyDeviceToHost,
+                                           c->copy_stream));
+            }
+        }
         HIPCHK(c, hipEventRecord(c->ev_d2h[k & 1], c->copy_stream));
         return DFX_OK;
     };
@@ -185,11 +229,24 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             c->h_pairs[j].frame_a = a % F;
             c->h_pairs[j].frame_b = b % F;
         }
-        float *dst = host_mode ? c->d_flow_out[k & 1] : d_flows + (size_t)p.i0 * d_flow_stride;
-        const long long dst_stride = host_mode ? (long long)c->W * c->H * 2 : (long long)d_flow_stride;
+        const bool staged = host_mode || out.quantized;
+        float *dst = staged ? c->d_flow_out[k & 1] : out.d_flows + (size_t)p.i0 * out.d_flow_stride;
+        const long long dst_stride = staged ? (long long)plane * 2 : (long long)out.d_flow_stride;
         rc = E->run_pairs(p.nb, c->h_pairs.data(), dst, dst_stride);
         if (rc != DFX_OK)
             return rc;
+        if (out.quantized) { // convertFlowToImage on the device (src/common.cpp:4-16)
+            if (host_mode)
+                quant_launch_flow_to_u8(c->stream, dst, dst_stride, p.nb, c->W, c->H, out.lo, out.hi, c->d_img[k & 1],
+                                        c->d_img[k & 1] + (size_t)c->img_slots * plane, c->W, (long long)plane);
+            else
+                quant_launch_flow_to_u8(c->stream, dst, dst_stride, p.nb, c->W, c->H, out.lo, out.hi,
+                                        out.d_img_x + (size_t)p.i0 * out.d_img_stride,
+                                        out.d_img_y + (size_t)p.i0 * out.d_img_stride, (long long)out.img_pitch,
+                                        (long long)out.d_img_stride);
+            HIPCHK(c, hipGetLastError());
+            c->stats.kernel_launches += 1;
+        }
         HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
         if (host_mode)
             HIPCHK(c, hipEventRecord(c->ev_compute[k & 1], c->stream));
@@ -350,7 +407,10 @@ int dfx_calc_batch(dfx_handle h, const uint8_t *const *frames, size_t frame_pitc
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or flows array");
     if (M > 0 && (frame_pitch < (size_t)h->W || out_pitch < (size_t)h->W * 8))
         return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
-    return calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, flows_uv, out_pitch, nullptr, 0);
+    OutSpec out;
+    out.flows = flows_uv;
+    out.out_pitch = out_pitch;
+    return calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, out);
 }
 
 int dfx_calc_batch_device(dfx_handle h, const uint8_t *d_frames, size_t pitch, size_t frame_stride, int n_frames,
@@ -363,8 +423,74 @@ int dfx_calc_batch_device(dfx_handle h, const uint8_t *d_frames, size_t pitch, s
     if (M > 0 && (pitch < (size_t)h->W || frame_stride < pitch * (size_t)h->H ||
                   flow_stride_floats < (size_t)h->W * h->H * 2))
         return dfx_fail(h, DFX_ERR_INVALID, "pitch/stride smaller than a frame");
-    return calc_batch_impl(h, nullptr, 0, d_frames, pitch, frame_stride, n_frames, step, nullptr, 0, d_flows,
-                           flow_stride_floats);
+    OutSpec out;
+    out.d_flows = d_flows;
+    out.d_flow_stride = flow_stride_floats;
+    return calc_batch_impl(h, nullptr, 0, d_frames, pitch, frame_stride, n_frames, step, out);
+}
+
+int dfx_calc_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
+                      double lower_bound, double upper_bound, uint8_t *const *img_x, uint8_t *const *img_y,
+                      size_t img_pitch) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    const int M = std::max(n_frames - std::abs(step), 0);
+    if (M > 0 && (!frames || !img_x || !img_y))
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or image plane array");
+    if (M > 0 && (frame_pitch < (size_t)h->W || img_pitch < (size_t)h->W))
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
+    OutSpec out;
+    out.quantized = true;
+    out.lo = lower_bound;
+    out.hi = upper_bound;
+    out.img_x = img_x;
+    out.img_y = img_y;
+    out.img_pitch = img_pitch;
+    return calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, out);
+}
+
+int dfx_calc_batch_u8_device(dfx_handle h, const uint8_t *d_frames, size_t pitch, size_t frame_stride, int n_frames,
+                             int step, double lower_bound, double upper_bound, uint8_t *d_img_x, uint8_t *d_img_y,
+                             size_t img_pitch, size_t img_stride) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    const int M = std::max(n_frames - std::abs(step), 0);
+    if (M > 0 && (!d_frames || !d_img_x || !d_img_y))
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL device frames or image planes");
+    if (M > 0 && (pitch < (size_t)h->W || frame_stride < pitch * (size_t)h->H || img_pitch < (size_t)h->W ||
+                  img_stride < img_pitch * (size_t)h->H))
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch/stride smaller than a frame");
+    OutSpec out;
+    out.quantized = true;
+    out.lo = lower_bound;
+    out.hi = upper_bound;
+    out.d_img_x = d_img_x;
+    out.d_img_y = d_img_y;
+    out.img_pitch = img_pitch;
+    out.d_img_stride = img_stride;
+    return calc_batch_impl(h, nullptr, 0, d_frames, pitch, frame_stride, n_frames, step, out);
+}
+
+int dfx_flow_to_u8_device(dfx_handle h, const float *d_flows, size_t flow_stride_floats, int n, double lower_bound,
+                          double upper_bound, uint8_t *d_img_x, uint8_t *d_img_y, size_t img_pitch,
+                          size_t img_stride) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    if (n < 0)
+        return dfx_fail(h, DFX_ERR_INVALID, "n must be >= 0");
+    if (n == 0)
+        return DFX_OK;
+    if (!d_flows || !d_img_x || !d_img_y)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL device flows or image planes");
+    if (flow_stride_floats < (size_t)h->W * h->H * 2 || img_pitch < (size_t)h->W ||
+        img_stride < img_pitch * (size_t)h->H)
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch/stride smaller than a frame");
+    HIPCHK(h, hipSetDevice(h->device));
+    quant_launch_flow_to_u8(h->stream, d_flows, (long long)flow_stride_floats, n, h->W, h->H, lower_bound,
+                            upper_bound, d_img_x, d_img_y, (long long)img_pitch, (long long)img_stride);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DFX_OK;
 }
 
 int dfx_get_stats(dfx_handle h, dfx_stats *out) {
@@ -395,6 +521,8 @@ void dfx_destroy(dfx_handle h) {
     for (auto &p : h->d_u8)
         dfx_free_dev(p);
     for (auto &p : h->d_flow_out)
+        dfx_free_dev(p);
+    for (auto &p : h->d_img)
         dfx_free_dev(p);
     for (auto &e : h->ev_h2d)
         if (e)

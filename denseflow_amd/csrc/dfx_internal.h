@@ -55,6 +55,8 @@ struct dfx_context {
     int u8_slots = 0;
     float *d_flow_out[2] = {nullptr, nullptr};   // flow_slots dense H*W*2 flows per set
     int flow_slots = 0;
+    unsigned char *d_img[2] = {nullptr, nullptr}; // bounded output: img_slots x planes, then img_slots y planes
+    int img_slots = 0;
     std::vector<int> h_slots;      // slot id of each new frame of the current batch
     std::vector<PairDesc> h_pairs; // descriptors of the current batch
 

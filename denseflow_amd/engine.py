@@ -149,6 +149,12 @@ def load_library():
     L.dfx_calc_batch.restype = i
     L.dfx_calc_batch_device.argtypes = [vp, vp, sz, sz, i, i, vp, sz]
     L.dfx_calc_batch_device.restype = i
+    L.dfx_calc_batch_u8.argtypes = [vp, C.POINTER(vp), sz, i, i, C.c_double, C.c_double, C.POINTER(vp), C.POINTER(vp), sz]
+    L.dfx_calc_batch_u8.restype = i
+    L.dfx_calc_batch_u8_device.argtypes = [vp, vp, sz, sz, i, i, C.c_double, C.c_double, vp, vp, sz, sz]
+    L.dfx_calc_batch_u8_device.restype = i
+    L.dfx_flow_to_u8_device.argtypes = [vp, vp, sz, i, C.c_double, C.c_double, vp, vp, sz, sz]
+    L.dfx_flow_to_u8_device.restype = i
     L.dfx_get_stats.argtypes = [vp, C.POINTER(DfxStats)]
     L.dfx_get_stats.restype = i
     L.dfx_reset_stats.argtypes = [vp]
@@ -270,6 +276,44 @@ class FlowEngine:
         """Frames and flows already resident in HBM (raw device pointers, e.g. torch .data_ptr())."""
         self._check(self._L.dfx_calc_batch_device(self._h, d_frames_ptr, pitch, frame_stride, n_frames, int(step),
                                                   d_flows_ptr, flow_stride_floats))
+
+    # -- flow bounding on the device (reference: convertFlowToImage, src/common.cpp:4-16) ------
+    def calc_optflows_u8(self, frames_gray, step: int, bound: float, lower: float | None = None):
+        """calc_optflows followed by encodeFlowMap's bounding (src/common.cpp:48-64), all on the device.
+
+        Returns (img_x, img_y): two lists of M (H, W) uint8 planes.  The reference bounds to
+        [-bound, bound]; pass `lower` for an asymmetric interval [lower, bound]."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
+        n = len(frames)
+        m = max(n - abs(step), 0)
+        img_x = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
+        img_y = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
+        if m == 0:
+            return img_x, img_y
+        for f in frames:
+            if f.shape != (self.height, self.width):
+                raise ValueError("frame shape does not match the engine")
+        lo = -float(bound) if lower is None else float(lower)
+        fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        xp = (C.c_void_p * m)(*[f.ctypes.data for f in img_x])
+        yp = (C.c_void_p * m)(*[f.ctypes.data for f in img_y])
+        self._check(self._L.dfx_calc_batch_u8(self._h, fp, self.width, n, int(step), lo, float(bound), xp, yp,
+                                              self.width))
+        return img_x, img_y
+
+    def calc_optflows_u8_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,
+                                lower: float, upper: float, d_img_x_ptr: int, d_img_y_ptr: int, img_pitch: int,
+                                img_stride: int):
+        """Frames and bounded planes resident in HBM (raw device pointers)."""
+        self._check(self._L.dfx_calc_batch_u8_device(self._h, d_frames_ptr, pitch, frame_stride, n_frames, int(step),
+                                                     float(lower), float(upper), d_img_x_ptr, d_img_y_ptr,
+                                                     img_pitch, img_stride))
+
+    def flow_to_u8_device(self, d_flows_ptr: int, flow_stride_floats: int, n: int, lower: float, upper: float,
+                          d_img_x_ptr: int, d_img_y_ptr: int, img_pitch: int, img_stride: int):
+        """Bound n flows that are already in device memory."""
+        self._check(self._L.dfx_flow_to_u8_device(self._h, d_flows_ptr, flow_stride_floats, int(n), float(lower),
+                                                  float(upper), d_img_x_ptr, d_img_y_ptr, img_pitch, img_stride))
 
     def stats(self) -> DfxStats:
         s = DfxStats()

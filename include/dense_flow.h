@@ -27,9 +27,12 @@ class FlowBuffer {
     path output_dir;
     int base_start;
     bool last_buffer;
-    FlowBuffer(vector<Mat> item_data, path output_dir, int base_start, bool last_buffer)
+    // Extension: flows already bounded to 8 bits on the device.  item_data then holds 2M CV_8UC1 planes,
+    // x and y alternating (flow i = item_data[2i], item_data[2i+1]), instead of M CV_32FC2 fields.
+    bool bounded;
+    FlowBuffer(vector<Mat> item_data, path output_dir, int base_start, bool last_buffer, bool bounded = false)
         : item_data(std::move(item_data)), output_dir(std::move(output_dir)), base_start(base_start),
-          last_buffer(last_buffer) {}
+          last_buffer(last_buffer), bounded(bounded) {}
 };
 
 // Bounded producer/consumer queue (the reference hand-rolls two of these with a mutex and two
@@ -65,6 +68,12 @@ class DenseFlow {
     bool has_class;
     bool is_record;
     int device;
+    // Extensions of the save stage.  device_bounding: for save_type "jpg" the flows are
+    // bounded to 8 bits on the GPU (dfx_calc_batch_u8) and the host only encodes; DF_HOST_BOUND=1 restores
+    // the reference's host-side convertFlowToImage.  encode_threads: JPEG/PNG encoders running in parallel
+    // inside encode_save (the reference encodes on one thread); DF_ENCODE_THREADS overrides.
+    bool device_bounding;
+    int encode_threads;
 
     int batch_maxsize;
     FlowBufferQueue frames_gray_queue;
@@ -107,8 +116,9 @@ class DenseFlow {
 
 // Test hook: drive the GPU operator on in-memory frames exactly as calc_optflows does.
 struct DenseFlowTestAccess {
+    // bounded = false: M CV_32FC2 flows; true: 2M CV_8UC1 planes bounded on the device (x, y alternating)
     static vector<Mat> run_calc_optflows_imp(DenseFlow &d, const vector<Mat> &frames_gray, const string &algorithm,
-                                             int step);
+                                             int step, bool bounded = false);
 };
 
 #endif // DENSEFLOW_DENSE_FLOW_H

@@ -13,6 +13,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_REF_QUANT_PATH = os.path.join(_HERE, "_ref", "libref_quant.so")
+REFERENCE_ROOT = "/root/reference"
 
 MAX_SCALES, MAX_WARPS, MAX_CHECKS = 16, 16, 8192
 
@@ -24,6 +26,12 @@ def build(force: bool = False) -> str:
     r = subprocess.run(["make", "-C", _HERE], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    if os.path.exists(os.path.join(REFERENCE_ROOT, "src", "common.cpp")):
+        # the reference's own convertFlowToImage, compiled where it lies (absent on the GPU box: the prebuilt
+        # oracle/_ref/libref_quant.so travels with the snapshot)
+        r = subprocess.run(["make", "-C", _HERE, "ref", "REF=" + REFERENCE_ROOT], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle/_ref build failed:\n" + r.stdout + r.stderr)
     return _LIB_PATH
 
 
@@ -99,6 +107,8 @@ def lib():
         L.orc_brox_calc.restype = C.c_int
         L.orc_brox_pyramid_sizes.argtypes = [C.c_int, C.c_int, C.POINTER(BroxParams), C.POINTER(C.c_int), C.c_int]
         L.orc_brox_pyramid_sizes.restype = C.c_int
+    if hasattr(L, "orc_flow_to_u8"):
+        L.orc_flow_to_u8.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p]
     _lib = L
     return L
 
@@ -218,3 +228,38 @@ def brox_calc(frame0: np.ndarray, frame1: np.ndarray, params: BroxParams | None 
     if rc != 0:
         raise ValueError("orc_brox_calc rejected the parameters")
     return flow
+
+
+# ---------------------------------------------------------------------------------------------- flow bounding
+def flow_to_u8(flow: np.ndarray, lower: float, upper: float):
+    """convertFlowToImage (reference src/common.cpp:4-16) on one (H, W, 2) float32 flow -> (img_x, img_y)."""
+    flow = np.ascontiguousarray(flow, dtype=np.float32)
+    h, w, _ = flow.shape
+    img_x = np.empty((h, w), np.uint8)
+    img_y = np.empty((h, w), np.uint8)
+    lib().orc_flow_to_u8(flow, w, h, float(lower), float(upper), img_x, img_y)
+    return img_x, img_y
+
+
+_ref_quant = None
+
+
+def ref_quant_available() -> bool:
+    return os.path.exists(_REF_QUANT_PATH)
+
+
+def ref_flow_to_u8(flow: np.ndarray, lower: float, upper: float):
+    """The same through the reference's own source lines (oracle/_ref/libref_quant.so, `make -C oracle ref`)."""
+    global _ref_quant
+    if _ref_quant is None:
+        R = C.CDLL(_REF_QUANT_PATH)
+        R.ref_convert_flow_to_image.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p]
+        _ref_quant = R
+    flow = np.asarray(flow, dtype=np.float32)
+    h, w, _ = flow.shape
+    fx = np.ascontiguousarray(flow[..., 0])
+    fy = np.ascontiguousarray(flow[..., 1])
+    img_x = np.empty((h, w), np.uint8)
+    img_y = np.empty((h, w), np.uint8)
+    _ref_quant.ref_convert_flow_to_image(fx, fy, w, h, float(lower), float(upper), img_x, img_y)
+    return img_x, img_y

@@ -67,6 +67,10 @@ DenseFlow::DenseFlow(vector<path> video_paths, vector<path> output_dirs, string 
       save_type(std::move(save_type)), step(step), bound(bound), new_width(new_width), new_height(new_height),
       new_short(new_short), has_class(has_class), is_record(is_record), device(device), batch_maxsize(512),
       frames_gray_queue(3), flows_queue(3), total_frames(0), total_flows(0), dfx_(nullptr) {
+    device_bounding = this->save_type == "jpg" && !std::getenv("DF_HOST_BOUND");
+    const char *et = std::getenv("DF_ENCODE_THREADS");
+    const int hw = (int)std::thread::hardware_concurrency();
+    encode_threads = et ? std::max(1, std::atoi(et)) : std::max(1, std::min(hw > 0 ? hw : 1, 16));
     if (!check_param())
         throw std::runtime_error("check init param error.");
 }
@@ -275,21 +279,39 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
             dfx_size_ = sz;
         }
         vector<const uint8_t *> in(N);
-        vector<float *> out(M);
         for (int i = 0; i < N; ++i)
             in[i] = frames_gray.item_data[i].ptr<uint8_t>();
-        for (int i = 0; i < M; ++i) {
-            flows[i].create(sz, CV_32FC2);
-            out[i] = flows[i].ptr<float>();
+        if (device_bounding) {
+            // encodeFlowMap's convertFlowToImage(-bound, bound) (src/common.cpp:52) happens on the device:
+            // two 8-bit planes per flow come back instead of a float field
+            flows.resize(2 * (size_t)M);
+            vector<uint8_t *> out_x(M), out_y(M);
+            for (int i = 0; i < M; ++i) {
+                flows[2 * i].create(sz, CV_8UC1);
+                flows[2 * i + 1].create(sz, CV_8UC1);
+                out_x[i] = flows[2 * i].ptr<uint8_t>();
+                out_y[i] = flows[2 * i + 1].ptr<uint8_t>();
+            }
+            if (dfx_calc_batch_u8(dfx_, in.data(), frames_gray.item_data[0].step, N, step, -bound, bound, out_x.data(),
+                                  out_y.data(), flows[0].step) != DFX_OK)
+                throw std::runtime_error(dfx_last_error(dfx_));
+        } else {
+            vector<float *> out(M);
+            for (int i = 0; i < M; ++i) {
+                flows[i].create(sz, CV_32FC2);
+                out[i] = flows[i].ptr<float>();
+            }
+            if (dfx_calc_batch(dfx_, in.data(), frames_gray.item_data[0].step, N, step, out.data(), flows[0].step) !=
+                DFX_OK)
+                throw std::runtime_error(dfx_last_error(dfx_));
         }
-        if (dfx_calc_batch(dfx_, in.data(), frames_gray.item_data[0].step, N, step, out.data(), flows[0].step) != DFX_OK)
-            throw std::runtime_error(dfx_last_error(dfx_));
         TRACE("calc: dfx_calc_batch done");
         total_flows += M;
     }
     if (verbose)
         cout << "flows queue push a item" << endl;
-    flows_queue.push(FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start, frames_gray.last_buffer),
+    flows_queue.push(FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start, frames_gray.last_buffer,
+                                device_bounding && M > 0),
                      is_final);
 }
 
@@ -311,29 +333,33 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
     while (true) {
         bool is_final = false;
         FlowBuffer flow_buffer = flows_queue.pop(&is_final);
-        const int M = (int)flow_buffer.item_data.size();
+        const int M = (int)flow_buffer.item_data.size() / (flow_buffer.bounded ? 2 : 1);
         TRACE("save: %d flows, base %d, final %d", M, flow_buffer.base_start, (int)is_final);
+        // The flows of a buffer are independent: the encoders run encode_threads wide (one thread in the
+        // reference, :414-437).  Files are still written in index order by this thread.
         if (save_type == "jpg") {
-            vector<vector<uchar>> output_x, output_y;
-            for (int i = 0; i < M; ++i) {
-                Mat planes[2];
-                split(flow_buffer.item_data[i], planes);
-                vector<uchar> str_x, str_y;
-                encodeFlowMap(planes[0], planes[1], str_x, str_y, bound);
-                output_x.push_back(std::move(str_x));
-                output_y.push_back(std::move(str_y));
+            vector<vector<uchar>> output_x(M), output_y(M);
+            if (flow_buffer.bounded) { // planes arrive bounded from the device: encode only
+                parallelFor(2 * M, encode_threads, [&](int k) {
+                    if (!imencodeJpeg(flow_buffer.item_data[k], (k & 1) ? output_y[k / 2] : output_x[k / 2]))
+                        throw std::runtime_error("JPEG encoder failed");
+                });
+            } else {
+                parallelFor(M, encode_threads, [&](int i) {
+                    Mat planes[2];
+                    split(flow_buffer.item_data[i], planes);
+                    encodeFlowMap(planes[0], planes[1], output_x[i], output_y[i], bound);
+                });
             }
             writeFlowImages(output_x, (flow_buffer.output_dir / "flow_x").string(), step, flow_buffer.base_start);
             writeFlowImages(output_y, (flow_buffer.output_dir / "flow_y").string(), step, flow_buffer.base_start);
         } else if (save_type == "png") {
-            vector<vector<uchar>> output;
-            for (int i = 0; i < M; ++i) {
+            vector<vector<uchar>> output(M);
+            parallelFor(M, encode_threads, [&](int i) {
                 Mat planes[2];
                 split(flow_buffer.item_data[i], planes);
-                vector<uchar> str;
-                encodeFlowMapPng(planes[0], planes[1], str);
-                output.push_back(std::move(str));
-            }
+                encodeFlowMapPng(planes[0], planes[1], output[i]);
+            });
             writeFlowImagesPng(output, (flow_buffer.output_dir / "flow").string(), step, flow_buffer.base_start);
         }
         // mark the video done after its last buffer has been written (resume support, :456-470)
@@ -436,7 +462,8 @@ void DenseFlow::launch(bool use_frames, string save_type, bool verbose) {
 }
 
 vector<Mat> DenseFlowTestAccess::run_calc_optflows_imp(DenseFlow &d, const vector<Mat> &frames_gray,
-                                                        const string &algorithm, int step) {
+                                                        const string &algorithm, int step, bool bounded) {
+    d.device_bounding = bounded;
     d.calc_optflows_imp(FlowBuffer(frames_gray, path(), 0, true), algorithm, step, false, true);
     bool fin = false;
     return d.flows_queue.pop(&fin).item_data;

@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "../include/dense_flow.h"
+#include "../include/utils.h"
 
 extern "C" {
 
@@ -56,5 +57,42 @@ int hh_calc_optflows_imp(const uchar *frames, int n, int w, int h, const char *a
         snprintf(err, err_cap, "%s", e.what());
         return -1;
     }
+}
+
+// The same with the bounding done on the device (what launch() does for save_type "jpg"):
+// planes: (n-|step|) x 2 x h x w bytes (x plane, then y plane, per flow).  Returns #flows or <0.
+int hh_calc_optflows_imp_bounded(const uchar *frames, int n, int w, int h, const char *algorithm, int step, int bound,
+                                 uchar *planes, char *err, int err_cap) {
+    try {
+        vector<path> none;
+        DenseFlow d(none, none, "tvl1", step, bound, 0, 0, 0, false, false, "jpg");
+        vector<Mat> fr(n);
+        for (int i = 0; i < n; ++i) {
+            fr[i].create(Size(w, h), CV_8UC1);
+            memcpy(fr[i].data(), frames + (size_t)i * w * h, (size_t)w * h);
+        }
+        vector<Mat> out = DenseFlowTestAccess::run_calc_optflows_imp(d, fr, algorithm, step, true);
+        for (size_t i = 0; i < out.size(); ++i)
+            memcpy(planes + i * (size_t)w * h, out[i].data(), (size_t)w * h);
+        return (int)out.size() / 2;
+    } catch (const std::exception &e) {
+        snprintf(err, err_cap, "%s", e.what());
+        return -1;
+    }
+}
+
+// parallelFor: sum of i over [0, n) computed on `threads` workers; throws_at >= 0 makes that index throw.
+long hh_parallel_sum(int n, int threads, int throws_at) {
+    std::atomic<long> sum(0);
+    try {
+        parallelFor(n, threads, [&](int i) {
+            if (i == throws_at)
+                throw std::runtime_error("boom");
+            sum += i;
+        });
+    } catch (const std::exception &) {
+        return -1;
+    }
+    return sum.load();
 }
 }

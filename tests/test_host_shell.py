@@ -187,6 +187,52 @@ def test_operator_matches_oracle_on_gpu(harness, oracle):
     assert m == -1 and err.value == b"NV hardware flow not enabled, pls recompile"
 
 
+def test_parallel_for_covers_every_index_and_propagates_errors(harness):
+    harness.hh_parallel_sum.restype = C.c_long
+    for n, threads in [(0, 4), (1, 8), (100, 1), (1000, 7), (5, 64)]:
+        assert harness.hh_parallel_sum(n, threads, -1) == n * (n - 1) // 2
+    assert harness.hh_parallel_sum(200, 6, 57) == -1  # the exception reaches the caller, nothing hangs
+    assert harness.hh_parallel_sum(200, 1, 199) == -1
+
+
+@pytest.mark.gpu
+def test_bounded_operator_matches_oracle_on_gpu(harness, oracle):
+    """save_type "jpg": calc_optflows_imp hands the save stage planes that were bounded on the device."""
+    w, h, n, step, bound = 96, 64, 5, 1, 20
+    frames = np.stack(SynthClip(w, h, 5).frames(n))
+    planes = np.zeros((n - 1, 2, h, w), np.uint8)
+    err = C.create_string_buffer(512)
+    harness.hh_calc_optflows_imp_bounded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int,
+                                                     C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+    refs = [oracle.flow_to_u8(oracle.tvl1_calc(frames[i], frames[i + 1]), -bound, bound) for i in range(n - 1)]
+    m = harness.hh_calc_optflows_imp_bounded(frames.ctypes.data, n, w, h, b"tvl1", step, bound, planes.ctypes.data,
+                                             err, 512)
+    assert m == n - 1, err.value
+    for i in range(m):
+        assert np.array_equal(planes[i, 0], refs[i][0]) and np.array_equal(planes[i, 1], refs[i][1])
+
+
+@pytest.mark.gpu
+def test_cli_device_bounding_writes_the_same_files_as_host_bounding(built, tmp_path):
+    """DF_HOST_BOUND=1 runs the reference's host-side convertFlowToImage; the default bounds on the GPU.
+    Both feed the same encoder, so the JPEG files must be identical byte for byte."""
+    w, h, n = 160, 120, 6
+    frames = SynthClip(w, h, 4).frames(n)
+    clip = tmp_path / "clip.y4m"
+    write_y4m(clip, frames)
+    lst = tmp_path / "list.txt"
+    lst.write_text(str(clip) + "\n")
+    outs = {}
+    for tag, env in (("dev", {}), ("host", {"DF_HOST_BOUND": "1", "DF_ENCODE_THREADS": "1"})):
+        r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / tag), "-a=farn", "-s=2", "-b=8"],
+                           capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+        files = sorted(p.name for p in (tmp_path / tag / "clip").iterdir())
+        outs[tag] = {f: (tmp_path / tag / "clip" / f).read_bytes() for f in files}
+    assert len(outs["dev"]) == 2 * (n - 2) and outs["dev"].keys() == outs["host"].keys()
+    assert all(outs["dev"][f] == outs["host"][f] for f in outs["dev"])
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end_on_gpu(built, oracle, tmp_path):
     """BASELINE config 1 shape: a 224x224 pair sequence, -a=tvl1 -s=1 -b=20, files named like the reference's."""

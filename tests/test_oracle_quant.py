@@ -1,0 +1,73 @@
+"""CPU checks of the flow-bounding oracle (oracle/quant_oracle.c = reference src/common.cpp:4-16).
+
+Pinned: the golden file was produced by the reference's own source lines (tests/golden/
+make_quant_golden.py), and when oracle/_ref/libref_quant.so is present the oracle is compared with it
+directly on fresh inputs as well.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import numpy_restatement as NR
+from tests.golden.make_quant_golden import CASES, adversarial_flow
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "quant_golden.npz")
+
+
+def test_known_answers(oracle):
+    f = np.zeros((1, 8, 2), np.float32)
+    f[0, :, 0] = [0.0, 20.0, -20.0, 20.000002, -20.000002, np.nan, np.inf, -np.inf]
+    f[0, :, 1] = [10.0, -10.0, 0.0392157, -0.0392157, 19.96, -19.96, 1e-30, 5.0]
+    x, y = oracle.flow_to_u8(f, -20, 20)
+    # 255*(0+20)/40 = 127.5 -> 128 (ties to even); the bounds map to 255 / 0; beyond them the clamps take over
+    assert x[0].tolist() == [128, 255, 0, 255, 0, 0, 255, 0]
+    # 255*30/40 = 191.25 -> 191 ; 255*10/40 = 63.75 -> 64 ; 127.75 -> 128 ; 127.25 -> 127 ; ... ; 159.375 -> 159
+    assert y[0].tolist() == [191, 64, 128, 127, 255, 0, 128, 159]
+
+
+def test_ties_round_to_even(oracle):
+    # bound 32: 255*(v+32)/64 hits k + 0.5 exactly when v = (2k+1)*32/255 - 32 is representable; use bound = 127.5:
+    # 255*(v+127.5)/255 = v + 127.5, so integers v give exact ties
+    v = np.arange(-127, 128, dtype=np.float32)
+    f = np.stack([v, v], -1)[None]
+    x, _ = oracle.flow_to_u8(f, -127.5, 127.5)
+    expect = np.rint(v.astype(np.float64) + 127.5).astype(np.uint8)  # numpy rint is half-to-even too
+    assert np.array_equal(x[0], expect)
+    assert x[0][0] == 0 and x[0][1] == 2 and x[0][2] == 2  # 0.5 -> 0, 1.5 -> 2, 2.5 -> 2
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_oracle_equals_reference_golden(oracle, case):
+    name = case[0]
+    g = np.load(GOLDEN)
+    bound = float(g[name + "_bound"][0])
+    x, y = oracle.flow_to_u8(g[name + "_flow"], -bound, bound)
+    assert np.array_equal(x, g[name + "_x"]) and np.array_equal(y, g[name + "_y"])
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_numpy_restatement_equals_reference_golden(case):
+    name = case[0]
+    g = np.load(GOLDEN)
+    bound = float(g[name + "_bound"][0])
+    x, y = NR.flow_to_u8(g[name + "_flow"], -bound, bound)
+    assert np.array_equal(x, g[name + "_x"]) and np.array_equal(y, g[name + "_y"])
+
+
+def test_golden_inputs_are_reproducible():
+    g = np.load(GOLDEN)
+    for name, bound, w, h, seed in CASES:
+        assert np.array_equal(adversarial_flow(bound, w, h, seed), g[name + "_flow"], equal_nan=True)
+
+
+def test_oracle_equals_compiled_reference_on_fresh_inputs(oracle):
+    if not oracle.ref_quant_available():
+        pytest.skip("oracle/_ref/libref_quant.so not built (needs /root/reference: make -C oracle ref)")
+    for seed, (lo, hi) in enumerate([(-20, 20), (-32, 32), (-1, 1), (-5, 20), (0, 0), (3, -3)]):
+        flow = adversarial_flow(max(abs(hi), 1), 80, 50, 100 + seed)
+        ox, oy = oracle.flow_to_u8(flow, lo, hi)
+        rx, ry = oracle.ref_flow_to_u8(flow, lo, hi)
+        assert np.array_equal(ox, rx) and np.array_equal(oy, ry), (lo, hi)
+        nx, ny = NR.flow_to_u8(flow, lo, hi)
+        assert np.array_equal(nx, rx) and np.array_equal(ny, ry), (lo, hi)
