@@ -4,7 +4,7 @@
 #   oracle: oracle/liboracle.so  (TEST INFRASTRUCTURE ONLY)
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
-CXXFLAGS ?= -O2 -std=c++17 -Wall -Wextra -fPIC -Iinclude
+CXXFLAGS ?= -O3 -std=c++17 -Wall -Wextra -fPIC -Iinclude
 CSRC     := $(wildcard denseflow_amd/csrc/*.hip denseflow_amd/csrc/*.cpp)
 CHDR     := $(wildcard denseflow_amd/csrc/*.h) include/dfx.h
 LIB      := denseflow_amd/lib/libdfx.so

@@ -28,6 +28,7 @@ bool imreadGray(const string &file, Mat &gray);          // .pgm (P5) / .ppm (P6
 void resizeLinear(const Mat &src, Mat &dst, Size size);  // bilinear, half-pixel centres (cv::resize default)
 
 bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality = 95); // baseline, 8-bit gray
+void imencodeJpegForcePortable(bool on); // testing aid: bypass the AVX2 transform
 bool imencodePng(const Mat &img, vector<uchar> &out);                     // 8-bit gray or BGR, stored deflate
 
 #endif

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""End-to-end rate of the host shell (build/denseflow): .y4m clip in, flow_x/flow_y JPEGs out.
+
+Measures what SURVEY.md §8f-1 is about: the save stage.  Three configurations per algorithm:
+  ref-like : DF_HOST_BOUND=1 DF_ENCODE_THREADS=1  (the reference's host-side bounding, one encoder thread)
+  host-par : DF_HOST_BOUND=1, default encoder threads
+  device   : bounding on the GPU (default), default encoder threads
+Usage: python scripts/e2e_cli_rate.py [W H NF] ; needs a GPU; writes under $TMPDIR.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from denseflow_amd.synth import SynthClip  # noqa: E402
+
+W, H, NF = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (1920, 1080, 129)))
+algos = os.environ.get("ALGOS", "farn,tvl1").split(",")
+exe = os.path.join(ROOT, "build", "denseflow")
+tmp = tempfile.mkdtemp(prefix="dfe2e_")
+clip = os.path.join(tmp, "clip.y4m")
+frames = SynthClip(W, H, 2).frames_torch(NF, torch.device("cuda", 0)).cpu().numpy()
+with open(clip, "wb") as f:
+    f.write(f"YUV4MPEG2 W{W} H{H} F30:1 Ip A1:1 Cmono\n".encode())
+    for fr in frames:
+        f.write(b"FRAME\n")
+        f.write(fr.tobytes())
+lst = os.path.join(tmp, "list.txt")
+open(lst, "w").write(clip + "\n")
+configs = [("ref-like", {"DF_HOST_BOUND": "1", "DF_ENCODE_THREADS": "1"}), ("host-par", {"DF_HOST_BOUND": "1"}),
+           ("device", {})]
+print(f"clip {W}x{H} x {NF} frames, host cores {os.cpu_count()}", flush=True)
+for algo in algos:
+    for tag, env in configs:
+        out = os.path.join(tmp, f"out_{algo}_{tag}")
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, lst, "-o=" + out, "-a=" + algo, "-s=1", "-b=20"], capture_output=True, text=True,
+                           env={**os.environ, **env})
+        dt = time.perf_counter() - t0
+        m = re.search(r"flow speed ([0-9.e+-]+)fps", r.stdout)
+        n_files = len(os.listdir(os.path.join(out, "clip"))) if r.returncode == 0 else 0
+        print(f"{algo:5s} {tag:9s}: rc={r.returncode} wall {dt:6.2f}s  files {n_files}  summary flow speed "
+              f"{m.group(1) if m else '?'} fps  ({(NF - 1) / dt:6.1f} pairs/s incl. process start-up)", flush=True)
+        shutil.rmtree(out, ignore_errors=True)
+shutil.rmtree(tmp, ignore_errors=True)

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <unordered_map>
 
 #include "image_io.h"
 
@@ -14,6 +15,50 @@ static bool g_page_locked = false;
 
 void Mat::setPageLocked(bool on) { g_page_locked = on; }
 
+namespace {
+// Page-locking a buffer costs a driver call that maps and pins its pages (around a millisecond for a
+// 1080p plane); the pipeline allocates three such buffers per flow.  Released buffers are therefore kept,
+// keyed by size, and handed out again: frames and flows of one video all have the same few sizes.
+class PinnedPool {
+  public:
+    void *get(size_t bytes) {
+        {
+            unique_lock<mutex> lock(mtx_);
+            auto it = free_.find(bytes);
+            if (it != free_.end()) {
+                void *p = it->second;
+                free_.erase(it);
+                pooled_ -= bytes;
+                return p;
+            }
+        }
+        void *p = nullptr;
+        return dfx_host_alloc(&p, bytes) == DFX_OK ? p : nullptr;
+    }
+    void put(void *p, size_t bytes) {
+        {
+            unique_lock<mutex> lock(mtx_);
+            if (pooled_ + bytes <= kMaxPooled) {
+                free_.emplace(bytes, p);
+                pooled_ += bytes;
+                return;
+            }
+        }
+        dfx_host_free(p);
+    }
+
+  private:
+    static constexpr size_t kMaxPooled = 6ull << 30;
+    mutex mtx_;
+    std::unordered_multimap<size_t, void *> free_;
+    size_t pooled_ = 0;
+};
+PinnedPool &pinned_pool() {
+    static PinnedPool *pool = new PinnedPool(); // never destroyed: buffers may outlive static destruction order
+    return *pool;
+}
+} // namespace
+
 void Mat::create(Size s, int type) {
     if (buf_ && rows == s.height && cols == s.width && type_ == type)
         return;
@@ -22,9 +67,9 @@ void Mat::create(Size s, int type) {
     type_ = type;
     step = (size_t)cols * elemSize();
     const size_t bytes = std::max<size_t>(step * rows, 1);
-    void *p = nullptr;
-    if (g_page_locked && dfx_host_alloc(&p, bytes) == DFX_OK && p) {
-        buf_.reset((uchar *)p, [](uchar *q) { dfx_host_free(q); });
+    void *p = g_page_locked ? pinned_pool().get(bytes) : nullptr;
+    if (p) {
+        buf_.reset((uchar *)p, [bytes](uchar *q) { pinned_pool().put(q, bytes); });
     } else {
         buf_.reset((uchar *)std::malloc(bytes), std::free);
     }

@@ -17,10 +17,15 @@
 
 // DF_TRACE=1: stage-by-stage trace on stderr (debugging aid; the reference has none)
 static const bool g_trace = std::getenv("DF_TRACE") != nullptr;
+static double trace_ms() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 #define TRACE(...)                                                                                              \
     do {                                                                                                        \
         if (g_trace) {                                                                                          \
-            fprintf(stderr, "[denseflow] " __VA_ARGS__);                                                        \
+            fprintf(stderr, "[denseflow %9.3f ms] ", trace_ms());                                               \
+            fprintf(stderr, __VA_ARGS__);                                                                       \
             fputc('\n', stderr);                                                                                \
             fflush(stderr);                                                                                     \
         }                                                                                                       \
@@ -70,7 +75,7 @@ DenseFlow::DenseFlow(vector<path> video_paths, vector<path> output_dirs, string 
     device_bounding = this->save_type == "jpg" && !std::getenv("DF_HOST_BOUND");
     const char *et = std::getenv("DF_ENCODE_THREADS");
     const int hw = (int)std::thread::hardware_concurrency();
-    encode_threads = et ? std::max(1, std::atoi(et)) : std::max(1, std::min(hw > 0 ? hw : 1, 16));
+    encode_threads = et ? std::max(1, std::atoi(et)) : std::max(1, std::min(hw > 0 ? hw : 1, 32));
     if (!check_param())
         throw std::runtime_error("check init param error.");
 }
@@ -143,6 +148,7 @@ bool DenseFlow::get_new_size(const VideoCapture &video_stream, const vector<path
             new_size = Size((int)std::round(width * 1.0 / height * new_short), new_short);
     } else {
         do_resize = false;
+        new_size = Size(width, height); // callers size their buffers from it
     }
     return do_resize;
 }
@@ -209,8 +215,11 @@ int DenseFlow::load_frames_video(VideoCapture &video_stream, vector<path> &frame
         video_flow_idx += M;
         if (!is_open)
             break;
+        // Drop the paths that were read.  (The reference erases M = read - |step| after the first buffer,
+        // :213-215, so an image directory with more than one buffer of frames gets |step| frames twice;
+        // deliberately not reproduced.)
         if (use_frames)
-            frames_path.erase(frames_path.begin(), frames_path.begin() + std::min<size_t>(M, frames_path.size()));
+            frames_path.erase(frames_path.begin(), frames_path.begin() + std::min(frames_gray.size(), frames_path.size()));
     }
     return video_flow_idx + astep;
 }
@@ -237,6 +246,13 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
         Size size;
         int frames_num;
         const bool do_resize = get_new_size(video_stream, frames_path, use_frames, size, frames_num);
+        // Frames per FlowBuffer.  The reference fixes 512 (include/dense_flow.h:33); the three stages only
+        // overlap across buffers, so large frames get shorter buffers (>= 2 device batches each): 64 frames at
+        // 1080p, 512 from 512x512 down.  Buffer boundaries do not change any flow (the last |step| frames
+        // are carried over, :204-207).
+        batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, (128ll << 20) / std::max(1ll, (long long)size.width * size.height)));
+        if (const char *bm = std::getenv("DF_BATCH_MAXSIZE")) // testing aid: force short buffers
+            batch_maxsize = std::max(1, std::atoi(bm));
         if (verbose)
             cout << video_path << ", frames ≈ " << frames_num << endl;
         const bool is_last = i == video_paths.size() - 1;
@@ -351,8 +367,10 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
                     encodeFlowMap(planes[0], planes[1], output_x[i], output_y[i], bound);
                 });
             }
+            TRACE("save: encoded");
             writeFlowImages(output_x, (flow_buffer.output_dir / "flow_x").string(), step, flow_buffer.base_start);
             writeFlowImages(output_y, (flow_buffer.output_dir / "flow_y").string(), step, flow_buffer.base_start);
+            TRACE("save: written");
         } else if (save_type == "png") {
             vector<vector<uchar>> output(M);
             parallelFor(M, encode_threads, [&](int i) {

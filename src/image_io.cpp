@@ -3,6 +3,10 @@
 // Host glue outside the hot path; nothing here runs on the GPU.
 #include "image_io.h"
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 #include <algorithm>
 #include <cmath>
 
@@ -180,19 +184,21 @@ struct HuffTable {
     }
 };
 
+// Entropy-coded segment writer: 64-bit accumulator, bytes appended to a raw buffer that the caller sized
+// for the worst case; 0xFF bytes get their stuffed zero as they leave the accumulator.
 struct BitWriter {
-    vector<uchar> &out;
-    unsigned acc = 0;
+    uchar *p;
+    unsigned long long acc = 0;
     int nbits = 0;
-    explicit BitWriter(vector<uchar> &o) : out(o) {}
-    void put(unsigned code, int len) {
+    explicit BitWriter(uchar *dst) : p(dst) {}
+    inline void put(unsigned code, int len) { // len <= 27
         acc = (acc << len) | (code & ((1u << len) - 1));
         nbits += len;
         while (nbits >= 8) {
             const uchar b = (uchar)(acc >> (nbits - 8));
-            out.push_back(b);
+            *p++ = b;
             if (b == 0xFF)
-                out.push_back(0);
+                *p++ = 0;
             nbits -= 8;
         }
     }
@@ -207,7 +213,100 @@ void put16(vector<uchar> &o, int v) {
     o.push_back((uchar)v);
 }
 
+// Forward DCT of one 8x8 block + quantisation.  c[v][y] is the DCT basis (row v = frequency), rq[v*8+u] the
+// reciprocal quantiser.  coef[v*8+u] in natural order.  Two implementations with the same arithmetic order
+// per output (sum over the 8 inputs in index order): a portable one, and AVX2+FMA intrinsics selected at run
+// time (the encoders of the save stage are the host-side bottleneck once the flows come bounded from the GPU).
+void load_block(const uchar *src, size_t pitch, int valid_w, int valid_h, float blk[8][8]) {
+    for (int y = 0; y < 8; ++y) { // ragged right / bottom edge: replicate the last column / row
+        const uchar *row = src + (size_t)std::min(y, valid_h - 1) * pitch;
+        for (int x = 0; x < 8; ++x)
+            blk[y][x] = (float)row[std::min(x, valid_w - 1)] - 128.f;
+    }
+}
+
+void fdct_quant_portable(const float blk[8][8], const float (*c)[8], const float *rq, int *coef) {
+    float t1[8][8]; // t1[v][x] = sum_y c[v][y] * blk[y][x]
+    for (int v = 0; v < 8; ++v)
+        for (int x = 0; x < 8; ++x) {
+            float s = 0;
+            for (int y = 0; y < 8; ++y)
+                s += c[v][y] * blk[y][x];
+            t1[v][x] = s;
+        }
+    for (int v = 0; v < 8; ++v)
+        for (int u = 0; u < 8; ++u) {
+            float s = 0;
+            for (int x = 0; x < 8; ++x)
+                s += c[u][x] * t1[v][x];
+            coef[v * 8 + u] = (int)std::lrintf(s * rq[v * 8 + u]);
+        }
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2,fma"))) inline void transpose8(__m256 r[8]) {
+    __m256 t0 = _mm256_unpacklo_ps(r[0], r[1]), t1 = _mm256_unpackhi_ps(r[0], r[1]);
+    __m256 t2 = _mm256_unpacklo_ps(r[2], r[3]), t3 = _mm256_unpackhi_ps(r[2], r[3]);
+    __m256 t4 = _mm256_unpacklo_ps(r[4], r[5]), t5 = _mm256_unpackhi_ps(r[4], r[5]);
+    __m256 t6 = _mm256_unpacklo_ps(r[6], r[7]), t7 = _mm256_unpackhi_ps(r[6], r[7]);
+    __m256 s0 = _mm256_shuffle_ps(t0, t2, 0x44), s1 = _mm256_shuffle_ps(t0, t2, 0xEE);
+    __m256 s2 = _mm256_shuffle_ps(t1, t3, 0x44), s3 = _mm256_shuffle_ps(t1, t3, 0xEE);
+    __m256 s4 = _mm256_shuffle_ps(t4, t6, 0x44), s5 = _mm256_shuffle_ps(t4, t6, 0xEE);
+    __m256 s6 = _mm256_shuffle_ps(t5, t7, 0x44), s7 = _mm256_shuffle_ps(t5, t7, 0xEE);
+    r[0] = _mm256_permute2f128_ps(s0, s4, 0x20), r[1] = _mm256_permute2f128_ps(s1, s5, 0x20);
+    r[2] = _mm256_permute2f128_ps(s2, s6, 0x20), r[3] = _mm256_permute2f128_ps(s3, s7, 0x20);
+    r[4] = _mm256_permute2f128_ps(s0, s4, 0x31), r[5] = _mm256_permute2f128_ps(s1, s5, 0x31);
+    r[6] = _mm256_permute2f128_ps(s2, s6, 0x31), r[7] = _mm256_permute2f128_ps(s3, s7, 0x31);
+}
+
+// out[v] = sum_y c[v][y] * in[y]  (each in[y] / out[v] is a row of 8 lanes)
+__attribute__((target("avx2,fma"))) inline void dct_rows(const __m256 in[8], const float (*c)[8], __m256 out[8]) {
+    for (int v = 0; v < 8; ++v) {
+        __m256 acc = _mm256_mul_ps(_mm256_broadcast_ss(&c[v][0]), in[0]);
+        for (int y = 1; y < 8; ++y)
+            acc = _mm256_fmadd_ps(_mm256_broadcast_ss(&c[v][y]), in[y], acc);
+        out[v] = acc;
+    }
+}
+
+__attribute__((target("avx2,fma"))) void fdct_quant_avx2(const uchar *src, size_t pitch, const float (*c)[8],
+                                                          const float *rq, int *coef) {
+    __m256 r[8], t[8];
+    const __m256 bias = _mm256_set1_ps(128.f);
+    for (int y = 0; y < 8; ++y) {
+        const __m128i b = _mm_loadl_epi64(reinterpret_cast<const __m128i *>(src + (size_t)y * pitch));
+        r[y] = _mm256_sub_ps(_mm256_cvtepi32_ps(_mm256_cvtepu8_epi32(b)), bias);
+    }
+    dct_rows(r, c, t); // t[v][x]: vertical frequencies
+    transpose8(t);     // t[x][v]
+    dct_rows(t, c, r); // r[u][v]: both
+    transpose8(r);     // r[v][u]
+    for (int v = 0; v < 8; ++v)
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(coef + 8 * v),
+                            _mm256_cvtps_epi32(_mm256_mul_ps(r[v], _mm256_loadu_ps(rq + 8 * v)))); // nearest even
+}
+const bool g_has_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+#endif
+bool g_force_portable = false;
+
+inline void fdct_quant(const uchar *src, size_t pitch, int valid_w, int valid_h, const float (*c)[8], const float *rq,
+                       int *coef) {
+#if defined(__x86_64__)
+    if (g_has_avx2 && !g_force_portable && valid_w >= 8 && valid_h >= 8) {
+        fdct_quant_avx2(src, pitch, c, rq, coef);
+        return;
+    }
+#endif
+    float blk[8][8];
+    load_block(src, pitch, valid_w, valid_h, blk);
+    fdct_quant_portable(blk, c, rq, coef);
+}
+
+inline int bit_length(int a) { return a ? 32 - __builtin_clz((unsigned)a) : 0; }
+
 } // namespace
+
+void imencodeJpegForcePortable(bool on) { g_force_portable = on; }
 
 bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
     if (gray.empty() || gray.type() != CV_8UC1)
@@ -215,22 +314,29 @@ bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
     quality = std::min(100, std::max(1, quality));
     const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
     uchar q[64];
-    for (int i = 0; i < 64; ++i)
+    float rq[64];
+    for (int i = 0; i < 64; ++i) {
         q[i] = (uchar)std::min(255, std::max(1, (kLumaQ[i] * scale + 50) / 100));
-    static HuffTable dc, ac;
-    static bool built = false;
-    static float cosv[8][8];
-    if (!built) {
-        dc.build(kDcBits, kDcVal);
-        ac.build(kAcBits, kAcVal);
-        for (int u = 0; u < 8; ++u)
-            for (int x = 0; x < 8; ++x)
-                cosv[u][x] = (float)(std::cos((2 * x + 1) * u * M_PI / 16.0) * (u == 0 ? std::sqrt(0.125) : 0.5));
-        built = true;
+        rq[i] = 1.0f / (float)q[i];
     }
+    struct Tables {
+        HuffTable dc, ac;
+        float c[8][8];      // c[u][x] = DCT-II basis, orthonormal
+        uchar nat2zig[64];  // position of natural-order coefficient i in the zig-zag scan
+        Tables() {
+            dc.build(kDcBits, kDcVal);
+            ac.build(kAcBits, kAcVal);
+            for (int u = 0; u < 8; ++u)
+                for (int x = 0; x < 8; ++x)
+                    c[u][x] = (float)(std::cos((2 * x + 1) * u * M_PI / 16.0) * (u == 0 ? std::sqrt(0.125) : 0.5));
+            for (int k = 0; k < 64; ++k)
+                nat2zig[kZigzag[k]] = (uchar)k;
+        }
+    };
+    static const Tables T; // thread-safe one-time initialisation: encoders run in parallel
+    const HuffTable &dc = T.dc, &ac = T.ac;
     const int W = gray.cols, H = gray.rows;
     out.clear();
-    out.reserve((size_t)W * H / 4 + 1024);
     const uchar soi_app0[] = {0xFF, 0xD8, 0xFF, 0xE0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
     out.insert(out.end(), soi_app0, soi_app0 + sizeof soi_app0);
     out.push_back(0xFF), out.push_back(0xDB), put16(out, 67), out.push_back(0);
@@ -245,69 +351,50 @@ bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
     const uchar sos[] = {0xFF, 0xDA, 0, 8, 1, 1, 0x00, 0, 63, 0};
     out.insert(out.end(), sos, sos + sizeof sos);
 
-    BitWriter bw(out);
+    // worst case per block: 64 coefficients x (16-bit code + 11 value bits) = 216 bytes, doubled by stuffing
+    const size_t blocks = (size_t)((W + 7) / 8) * ((H + 7) / 8);
+    // per-thread scratch for the entropy-coded segment (kept across calls: no page faults, no zero fill)
+    static thread_local vector<uchar> scratch;
+    if (scratch.size() < blocks * 432 + 16)
+        scratch.resize(blocks * 432 + 16);
+    BitWriter bw(scratch.data());
     int prev_dc = 0;
     for (int by = 0; by < H; by += 8) {
         for (int bx = 0; bx < W; bx += 8) {
-            float blk[8][8], tmp[8][8];
-            for (int y = 0; y < 8; ++y) {
-                const uchar *row = gray.ptr<uchar>(std::min(by + y, H - 1));
-                for (int x = 0; x < 8; ++x)
-                    blk[y][x] = (float)row[std::min(bx + x, W - 1)] - 128.f;
-            }
-            for (int y = 0; y < 8; ++y)
-                for (int u = 0; u < 8; ++u) {
-                    float s = 0;
-                    for (int x = 0; x < 8; ++x)
-                        s += blk[y][x] * cosv[u][x];
-                    tmp[y][u] = s;
-                }
-            int coef[64];
-            for (int v = 0; v < 8; ++v)
-                for (int u = 0; u < 8; ++u) {
-                    float s = 0;
-                    for (int y = 0; y < 8; ++y)
-                        s += tmp[y][u] * cosv[v][y];
-                    coef[v * 8 + u] = (int)std::lrintf(s / q[v * 8 + u]);
-                }
-            // DC
-            int diff = coef[0] - prev_dc;
+            alignas(32) int coef[64];
+            fdct_quant(gray.ptr<uchar>(by) + bx, gray.step, W - bx, H - by, T.c, rq, coef);
+            // DC difference
+            const int diff = coef[0] - prev_dc;
             prev_dc = coef[0];
-            int a = diff < 0 ? -diff : diff, nb = 0;
-            while (a) {
-                ++nb;
-                a >>= 1;
-            }
+            const int nb = bit_length(diff < 0 ? -diff : diff);
             bw.put(dc.code[nb], dc.len[nb]);
             if (nb)
                 bw.put((unsigned)(diff < 0 ? diff - 1 : diff), nb);
-            // AC
-            int run = 0;
-            for (int k = 1; k < 64; ++k) {
-                const int v = coef[kZigzag[k]];
-                if (v == 0) {
-                    ++run;
-                    continue;
-                }
+            // AC run lengths over the zig-zag scan: visit only the non-zero coefficients
+            unsigned long long nz = 0; // bit k: zig-zag position k holds a non-zero coefficient
+            for (int i = 1; i < 64; ++i)
+                nz |= (unsigned long long)(coef[i] != 0) << T.nat2zig[i];
+            int last = 0;
+            while (nz) {
+                const int k = __builtin_ctzll(nz);
+                nz &= nz - 1;
+                int run = k - last - 1;
+                last = k;
                 while (run > 15) {
                     bw.put(ac.code[0xF0], ac.len[0xF0]);
                     run -= 16;
                 }
-                int av = v < 0 ? -v : v, n = 0;
-                while (av) {
-                    ++n;
-                    av >>= 1;
-                }
+                const int v = coef[kZigzag[k]];
+                const int n = bit_length(v < 0 ? -v : v);
                 const int sym = (run << 4) | n;
-                bw.put(ac.code[sym], ac.len[sym]);
-                bw.put((unsigned)(v < 0 ? v - 1 : v), n);
-                run = 0;
+                bw.put(((unsigned)ac.code[sym] << n) | ((unsigned)(v < 0 ? v - 1 : v) & ((1u << n) - 1)), ac.len[sym] + n);
             }
-            if (run)
+            if (last != 63)
                 bw.put(ac.code[0x00], ac.len[0x00]);
         }
     }
     bw.flush();
+    out.insert(out.end(), scratch.data(), bw.p);
     out.push_back(0xFF), out.push_back(0xD9);
     return true;
 }

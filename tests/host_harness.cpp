@@ -7,6 +7,8 @@
 
 extern "C" {
 
+void hh_jpeg_force_portable(int on) { imencodeJpegForcePortable(on != 0); }
+
 int hh_encode_jpeg(const uchar *gray, int w, int h, int quality, uchar *out, int out_cap) {
     Mat m(Size(w, h), CV_8UC1);
     memcpy(m.data(), gray, (size_t)w * h);

@@ -144,6 +144,30 @@ def test_quantisation_cast_formula(harness):
     assert list(ox[0, :4]) == [0, 255, 128, 255]
 
 
+@pytest.mark.parametrize("w,h", [(70, 45), (64, 64), (257, 131), (8, 8), (5, 3)])
+def test_jpeg_transform_paths_agree_and_decode(harness, w, h):
+    """The AVX2 and the portable forward DCT feed the same entropy coder; both must decode to the image."""
+    from PIL import Image
+
+    rng = np.random.default_rng(w * 1000 + h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    gray = np.clip(128 + 60 * np.sin(xx / 9.0) * np.cos(yy / 7.0) + rng.normal(0, 6, (h, w)), 0, 255).astype(np.uint8)
+    buf = np.zeros(1 << 20, np.uint8)
+    dec = {}
+    for name, portable in (("simd", 0), ("portable", 1)):
+        harness.hh_jpeg_force_portable(portable)
+        for quality in (95, 50):
+            n = harness.hh_encode_jpeg(gray.ctypes.data_as(C.c_void_p), w, h, quality, buf.ctypes.data_as(C.c_void_p),
+                                       buf.size)
+            assert n > 0
+            dec[name, quality] = np.array(Image.open(io.BytesIO(buf[:n].tobytes()))).astype(int)
+            assert dec[name, quality].shape == (h, w)
+    harness.hh_jpeg_force_portable(0)
+    assert np.abs(dec["simd", 95] - gray).mean() < 2.0 and np.abs(dec["portable", 95] - gray).mean() < 2.0
+    for quality in (95, 50):  # same coefficients up to rounding ties -> essentially the same picture
+        assert np.abs(dec["simd", quality] - dec["portable", quality]).mean() < 0.1
+
+
 def test_png_and_jpeg_encoders_round_trip(harness):
     from PIL import Image
 
@@ -231,6 +255,44 @@ def test_cli_device_bounding_writes_the_same_files_as_host_bounding(built, tmp_p
         outs[tag] = {f: (tmp_path / tag / "clip" / f).read_bytes() for f in files}
     assert len(outs["dev"]) == 2 * (n - 2) and outs["dev"].keys() == outs["host"].keys()
     assert all(outs["dev"][f] == outs["host"][f] for f in outs["dev"])
+
+
+def _write_pgm_dir(d, frames):
+    d.mkdir(parents=True)
+    for i, fr in enumerate(frames):
+        with open(d / f"img_{i:05d}.pgm", "wb") as f:
+            f.write(f"P5\n{fr.shape[1]} {fr.shape[0]}\n255\n".encode())
+            f.write(np.ascontiguousarray(fr, np.uint8).tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["video", "frames"])
+@pytest.mark.parametrize("step", [1, 2])
+def test_buffer_boundaries_do_not_change_the_output(built, tmp_path, source, step):
+    """FlowBuffers are a pipelining unit only: cutting a video into short buffers (carrying |step| frames over,
+    reference :204-207) must give the files of a single-buffer run, for clips and for image directories."""
+    w, h, n = 64, 48, 11
+    frames = SynthClip(w, h, 9).frames(n)
+    if source == "video":
+        src = tmp_path / "clip.y4m"
+        write_y4m(src, frames)
+        extra = []
+    else:
+        src = tmp_path / "clip"
+        _write_pgm_dir(src, frames)
+        extra = ["-if"]
+    lst = tmp_path / "list.txt"
+    lst.write_text(str(src) + "\n")
+    outs = {}
+    for tag, bm in (("one", "512"), ("cut", "4"), ("cut3", "3")):
+        r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / tag), "-a=farn", f"-s={step}", "-b=8"] + extra,
+                           capture_output=True, text=True, env={**os.environ, "DF_BATCH_MAXSIZE": bm})
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"({n} frames, {n - step} farn flows)" in r.stdout, r.stdout
+        d = tmp_path / tag / "clip"
+        outs[tag] = {p.name: p.read_bytes() for p in sorted(d.iterdir())}
+    assert len(outs["one"]) == 2 * (n - step)
+    assert outs["cut"] == outs["one"] and outs["cut3"] == outs["one"]
 
 
 @pytest.mark.gpu
