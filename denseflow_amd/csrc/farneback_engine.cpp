@@ -309,7 +309,7 @@ int FarnebackEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, lo
         HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
         for (int it = 0; it < p.farn_num_iters; ++it) {
             const int dm = it < p.farn_num_iters - 1;
-            farn_launch_iteration(c->stream, x, cur, m_src, half, box_inv, dm);
+            farn_launch_iteration(c->stream, x, cur, m_src, half, box_inv, dm, c->prm.impl);
             if (dm)
                 m_src ^= 1;
         }

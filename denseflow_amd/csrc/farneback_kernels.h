@@ -57,5 +57,5 @@ void farn_launch_init_flow(hipStream_t s, const FarnPairCtx &c, int cur_set, int
 void farn_launch_update_matrices(hipStream_t s, const FarnPairCtx &c, int flow_set, int m_set);
 // boxFilter5 + updateFlow (+ updateMatrices) in one launch (B.8, B.9, B.7)
 void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, int m_src, int half, float box_inv,
-                           int do_matrices);
+                           int do_matrices, int impl);
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride);

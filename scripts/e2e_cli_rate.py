@@ -22,21 +22,25 @@ import torch  # noqa: E402
 from denseflow_amd.synth import SynthClip  # noqa: E402
 
 W, H, NF = (int(v) for v in (sys.argv[1:4] if len(sys.argv) >= 4 else (1920, 1080, 129)))
+NCLIPS = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # BASELINE config 4 shape: many short clips in one list
 algos = os.environ.get("ALGOS", "farn,tvl1").split(",")
 exe = os.path.join(ROOT, "build", "denseflow")
 tmp = tempfile.mkdtemp(prefix="dfe2e_")
-clip = os.path.join(tmp, "clip.y4m")
-frames = SynthClip(W, H, 2).frames_torch(NF, torch.device("cuda", 0)).cpu().numpy()
-with open(clip, "wb") as f:
-    f.write(f"YUV4MPEG2 W{W} H{H} F30:1 Ip A1:1 Cmono\n".encode())
-    for fr in frames:
-        f.write(b"FRAME\n")
-        f.write(fr.tobytes())
+clips = []
+for c in range(NCLIPS):
+    clip = os.path.join(tmp, "clip.y4m" if NCLIPS == 1 else f"clip{c:04d}.y4m")
+    frames = SynthClip(W, H, 2 if NCLIPS == 1 else 1000 + c).frames_torch(NF, torch.device("cuda", 0)).cpu().numpy()
+    with open(clip, "wb") as f:
+        f.write(f"YUV4MPEG2 W{W} H{H} F30:1 Ip A1:1 Cmono\n".encode())
+        for fr in frames:
+            f.write(b"FRAME\n")
+            f.write(fr.tobytes())
+    clips.append(clip)
 lst = os.path.join(tmp, "list.txt")
-open(lst, "w").write(clip + "\n")
+open(lst, "w").write("".join(c + "\n" for c in clips))
 configs = [("ref-like", {"DF_HOST_BOUND": "1", "DF_ENCODE_THREADS": "1"}), ("host-par", {"DF_HOST_BOUND": "1"}),
            ("device", {})]
-print(f"clip {W}x{H} x {NF} frames, host cores {os.cpu_count()}", flush=True)
+print(f"{NCLIPS} clip(s) {W}x{H} x {NF} frames, host cores {os.cpu_count()}", flush=True)
 for algo in algos:
     for tag, env in configs:
         out = os.path.join(tmp, f"out_{algo}_{tag}")
@@ -45,8 +49,8 @@ for algo in algos:
                            env={**os.environ, **env})
         dt = time.perf_counter() - t0
         m = re.search(r"flow speed ([0-9.e+-]+)fps", r.stdout)
-        n_files = len(os.listdir(os.path.join(out, "clip"))) if r.returncode == 0 else 0
+        n_files = sum(len(fs) for _, _, fs in os.walk(out)) if r.returncode == 0 else 0
         print(f"{algo:5s} {tag:9s}: rc={r.returncode} wall {dt:6.2f}s  files {n_files}  summary flow speed "
-              f"{m.group(1) if m else '?'} fps  ({(NF - 1) / dt:6.1f} pairs/s incl. process start-up)", flush=True)
+              f"{m.group(1) if m else '?'} fps  ({NCLIPS * (NF - 1) / dt:6.1f} pairs/s incl. process start-up)", flush=True)
         shutil.rmtree(out, ignore_errors=True)
 shutil.rmtree(tmp, ignore_errors=True)
