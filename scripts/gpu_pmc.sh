@@ -1,33 +1,41 @@
 #!/bin/bash
-# PMC passes (FETCH_SIZE, WRITE_SIZE in separate runs, kernel-trace only) for the bench workload
+# HBM traffic of the dominant kernels from the PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE passes,
+# kernel-trace only (MI355X_MICROARCH.md §HBM).  Short workload (34 frames, batches of 16): rocprofv3 --pmc was
+# unstable on longer runs on this pool.  Writes gpurun_out/pmc_traffic.json in the layout of profiles/pmc_traffic.json.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+ALGOS=${ALGOS:-"tvl1 farn"}
 cd /tmp
-for A in tvl1 farn; do
+for A in $ALGOS; do
 for CNT in FETCH_SIZE WRITE_SIZE; do
-  ( timeout 600 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $R/gpurun_out/pmc_${A}_$CNT -o p -- python $R/bench.py --algo $A --steps 1 --warmup 0 --frames 66 --no-cpu-baseline ) > $R/gpurun_out/pmc_${A}_$CNT.log 2>&1; echo "pmc $A $CNT rc=$?"
+  ( timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $R/gpurun_out/pmc_${A}_$CNT -o p -- python $R/bench.py --algo $A --steps 1 --warmup 0 --frames 34 --max-batch 16 --no-cpu-baseline ) > $R/gpurun_out/pmc_${A}_$CNT.log 2>&1; echo "pmc $A $CNT rc=$?"
 done; done
 cd $R
-python - <<'PY'
-import csv,glob,collections,json
+ALGOS="$ALGOS" python - <<'PY'
+import csv,glob,collections,json,os
+dom={"tvl1":"void k_tvl1_step_fused<32>","farn":"void k_farn_iteration_t<6>","brox":"k_brox_sor_fused"}
 out={}
-for A in ("tvl1","farn"):
-    res={}
+for A in os.environ["ALGOS"].split():
+    per={}
     for CNT in ("FETCH_SIZE","WRITE_SIZE"):
-        fs=glob.glob(f"gpurun_out/pmc_{A}_{CNT}/*counter_collection.csv")
+        fs=glob.glob(f"gpurun_out/pmc_{A}_{CNT}/**/*counter_collection.csv", recursive=True)
         if not fs: print("no csv",A,CNT); continue
         agg=collections.defaultdict(lambda:[0,0.0])
         for r in csv.DictReader(open(fs[0])):
             if r.get("Counter_Name")!=CNT: continue
             k=r["Kernel_Name"].split("(")[0]
             agg[k][0]+=1; agg[k][1]+=float(r["Counter_Value"])
-        res[CNT]={k:{"launches":v[0],"sum":v[1],"per_launch":v[1]/max(v[0],1)} for k,v in agg.items() if k.startswith(("k_","void k_"))}
-    out[A]=res
-json.dump(out,open("gpurun_out/pmc_summary.json","w"),indent=1)
-for A,res in out.items():
-    for CNT,d in res.items():
-        for k,v in sorted(d.items(), key=lambda kv:-kv[1]["sum"])[:4]:
-            print(A,CNT,k[:40],v)
+        for k,v in sorted(agg.items(), key=lambda kv:-kv[1][1])[:5]:
+            print(A,CNT,k[:50],v)
+        per[CNT]=agg.get(dom[A])
+    if per.get("FETCH_SIZE") and per.get("WRITE_SIZE"):
+        n=per["FETCH_SIZE"][0]; f=per["FETCH_SIZE"][1]/n; w=per["WRITE_SIZE"][1]/per["WRITE_SIZE"][0]
+        b=(2*f+w)*1024
+        out[A]={"kernel":dom[A],"launches":n,"FETCH_SIZE_KB_per_launch":f,"WRITE_SIZE_KB_per_launch":w,
+                "hbm_bytes_per_launch":b,"measured_batch":16,"hbm_bytes_per_launch_per_pair":b/16,
+                "workload":"1920x1080, 34 frames (33 pairs, batches of 16/16/1), 1 GPU"}
+json.dump(out,open("gpurun_out/pmc_traffic.json","w"),indent=1)
+print(json.dumps(out,indent=1))
 PY
 rm -rf gpurun_out/pmc_*_FETCH_SIZE gpurun_out/pmc_*_WRITE_SIZE

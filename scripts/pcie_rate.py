@@ -34,11 +34,23 @@ def host_path():
     assert rc == 0, L.dfx_last_error(eng._h)
 
 
+h_x = torch.empty((NF - 1, H, W), dtype=torch.uint8, pin_memory=True)
+h_y = torch.empty((NF - 1, H, W), dtype=torch.uint8, pin_memory=True)
+xp = (C.c_void_p * (NF - 1))(*[h_x[i].data_ptr() for i in range(NF - 1)])
+yp = (C.c_void_p * (NF - 1))(*[h_y[i].data_ptr() for i in range(NF - 1)])
+
+
+def host_path_u8():  # flows bounded to [-20, 20] on the device: 2 B/px come down instead of 8
+    rc = L.dfx_calc_batch_u8(eng._h, fp, W, NF, 1, -20.0, 20.0, xp, yp, W)
+    assert rc == 0, L.dfx_last_error(eng._h)
+
+
 def device_path():
     eng.calc_optflows_device(d_frames.data_ptr(), W, W * H, NF, 1, d_flows.data_ptr(), W * H * 2)
 
 
-for name, fn in (("HBM-resident", device_path), ("PCIe-inclusive (pinned host in/out)", host_path)):
+for name, fn in (("HBM-resident", device_path), ("PCIe-inclusive (pinned host in/out)", host_path),
+                 ("PCIe-inclusive, bounded 8-bit planes out", host_path_u8)):
     fn()
     t0 = time.perf_counter()
     fn()
