@@ -49,9 +49,10 @@ __global__ __launch_bounds__(256) void k_farn_u8_to_f32(const unsigned char *src
 
 // tmpv[z][2*dy + r][x] = vertical Gaussian pass (B.4) of frame z at source row (r ? y2r : y1r) of
 // destination row dy (E.1 row mapping), all full-resolution columns x.
-__global__ __launch_bounds__(256) void k_farn_blur_v(const float *frames, long long frame_stride, int W, int H,
-                                                     int pitch0, int dst_h, float ify, const float *ker, int half,
-                                                     float *tmpv, long long tmpv_frame_stride) {
+__global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ frames, long long frame_stride, int W,
+                                                     int H, int pitch0, int dst_h, float ify,
+                                                     const float *__restrict__ ker, int half,
+                                                     float *__restrict__ tmpv, long long tmpv_frame_stride) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int q = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || q >= 2 * dst_h)
@@ -61,21 +62,31 @@ __global__ __launch_bounds__(256) void k_farn_blur_v(const float *frames, long l
     const int y1 = (int)floorf(sy);
     const int yr = r ? min(y1 + 1, H - 1) : min(y1, H - 1);
     const float *src = frames + (long long)blockIdx.z * frame_stride;
-    float v = src[(long long)yr * pitch0 + x] * ker[0];
-    for (int j = 1; j <= half; ++j) {
-        const float a = src[(long long)reflect101_low(yr - j, H - 1) * pitch0 + x];
-        const float b = src[(long long)reflect101_high(yr + j, H - 1) * pitch0 + x];
-        v = v + (a + b) * ker[j];
+    const float *centre = src + (long long)yr * pitch0 + x;
+    float v = centre[0] * ker[0];
+    if (yr - half >= 0 && yr + half <= H - 1) {
+        // window inside the frame (all but the first/last `half` rows): no border arithmetic per tap —
+        // BORDER_REFLECT_101 costs two integer modulos per tap pair, more than the tap itself
+#pragma unroll 8 // the taps are independent loads: let 16 of them be in flight per accumulation step
+        for (int j = 1; j <= half; ++j)
+            v = v + (centre[-(long long)j * pitch0] + centre[(long long)j * pitch0]) * ker[j];
+    } else {
+        for (int j = 1; j <= half; ++j) {
+            const float a = src[(long long)reflect101_low(yr - j, H - 1) * pitch0 + x];
+            const float b = src[(long long)reflect101_high(yr + j, H - 1) * pitch0 + x];
+            v = v + (a + b) * ker[j];
+        }
     }
     tmpv[(long long)blockIdx.z * tmpv_frame_stride + (long long)q * pitch0 + x] = v;
 }
 
 // pyr[z][dy][dx] = bilinear (E.1) of the blurred frame, the blur's horizontal pass (B.4) being
 // evaluated only at the two source columns this pixel samples.
-__global__ __launch_bounds__(256) void k_farn_blur_h_resize(const float *tmpv, long long tmpv_frame_stride, int W,
-                                                            int H, int pitch0, int dst_w, int dst_h, int dst_pitch,
-                                                            float ifx, float ify, const float *ker, int half,
-                                                            float *pyr, long long pyr_frame_stride) {
+__global__ __launch_bounds__(256) void k_farn_blur_h_resize(const float *__restrict__ tmpv,
+                                                            long long tmpv_frame_stride, int W, int H, int pitch0,
+                                                            int dst_w, int dst_h, int dst_pitch, float ifx, float ify,
+                                                            const float *__restrict__ ker, int half,
+                                                            float *__restrict__ pyr, long long pyr_frame_stride) {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= dst_w || dy >= dst_h)
@@ -93,8 +104,14 @@ __global__ __launch_bounds__(256) void k_farn_blur_h_resize(const float *tmpv, l
         for (int k = 0; k < 2; ++k) {
             const int cx = xc[k];
             float res = row[cx] * ker[0];
-            for (int i = 1; i <= half; ++i)
-                res = res + (row[reflect101(cx - i, W - 1)] + row[reflect101(cx + i, W - 1)]) * ker[i];
+            if (cx - half >= 0 && cx + half <= W - 1) { // window inside the row: plain indices
+#pragma unroll 8
+                for (int i = 1; i <= half; ++i)
+                    res = res + (row[cx - i] + row[cx + i]) * ker[i];
+            } else {
+                for (int i = 1; i <= half; ++i)
+                    res = res + (row[reflect101(cx - i, W - 1)] + row[reflect101(cx + i, W - 1)]) * ker[i];
+            }
             bl[r][k] = res;
         }
     }
