@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "dfx_internal.h"
+#include "prepare_kernels.h"
 #include "quantize_kernels.h"
 
 namespace {
@@ -56,6 +57,20 @@ int ensure_img_staging(dfx_context *c, int img_need) {
             HIPCHK(c, hipMalloc(&p, (size_t)img_need * 2 * c->W * c->H)); // img_need x planes, then the y planes
         }
         c->img_slots = img_need;
+    }
+    return DFX_OK;
+}
+
+int ensure_src_staging(dfx_context *c, int need) {
+    const size_t fb = c->in_row_bytes() * c->in_h();
+    if (need > c->src_slots || fb != c->src_frame_bytes) {
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto &p : c->d_src) {
+            dfx_free_dev(p);
+            HIPCHK(c, hipMalloc(&p, (size_t)need * fb));
+        }
+        c->src_slots = need;
+        c->src_frame_bytes = fb;
     }
     return DFX_OK;
 }
@@ -125,9 +140,15 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     const bool host_mode = frames != nullptr;
     // float flows land in the caller's device array, or in a staging set when they are copied to the host
     // or only feed the bounding kernel
-    rc = ensure_staging(c, host_mode ? B + astep : 0, (host_mode || out.quantized) ? B : 0);
+    const bool prep = c->prepares(); // inputs are source-format frames: convert / resize them on the device first
+    rc = ensure_staging(c, (host_mode || prep) ? B + astep : 0, (host_mode || out.quantized) ? B : 0);
     if (rc != DFX_OK)
         return rc;
+    if (prep && host_mode) {
+        rc = ensure_src_staging(c, B + astep);
+        if (rc != DFX_OK)
+            return rc;
+    }
     if (out.quantized && host_mode) {
         rc = ensure_img_staging(c, B);
         if (rc != DFX_OK)
@@ -156,10 +177,11 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     }
     auto upload = [&](size_t k) -> int { // host frames of batch k -> staging set k&1 (copy stream)
         const BatchPlan &p = plan[k];
-        unsigned char *dst = c->d_u8[k & 1];
+        const size_t rb = c->in_row_bytes(), fb = rb * c->in_h();
+        unsigned char *dst = prep ? c->d_src[k & 1] : c->d_u8[k & 1];
         for (int j = 0; j < p.n_new; ++j)
-            HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)j * c->W * c->H, c->W, frames[p.first_new + j], frame_pitch, c->W,
-                                       c->H, hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)j * fb, rb, frames[p.first_new + j], frame_pitch, rb, c->in_h(),
+                                       hipMemcpyHostToDevice, c->copy_stream));
         HIPCHK(c, hipEventRecord(c->ev_h2d[k & 1], c->copy_stream));
         return DFX_OK;
     };
@@ -213,7 +235,19 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         for (int j = 0; j < p.n_new; ++j)
             c->h_slots[j] = (int)((p.first_new + j) % F);
         if (p.n_new > 0) {
-            if (host_mode)
+            if (prep) { // cvtColor + cv::resize of load_frames_batch (src/denseflow_gpu.cpp:163, :169), on the device
+                if (host_mode)
+                    prepare_launch(c->stream, c->d_src[k & 1], (long long)c->in_row_bytes(),
+                                   (long long)c->src_frame_bytes, c->src_w, c->src_h, c->src_ch, p.n_new,
+                                   c->d_u8[k & 1], c->W, (long long)plane, c->W, c->H);
+                else
+                    prepare_launch(c->stream, d_frames + (size_t)p.first_new * d_frame_stride, (long long)d_pitch,
+                                   (long long)d_frame_stride, c->src_w, c->src_h, c->src_ch, p.n_new, c->d_u8[k & 1],
+                                   c->W, (long long)plane, c->W, c->H);
+                HIPCHK(c, hipGetLastError());
+                c->stats.kernel_launches += 1;
+            }
+            if (host_mode || prep)
                 rc = E->build_frames(c->d_u8[k & 1], (long long)c->W * c->H, c->W, p.n_new, c->h_slots.data());
             else
                 rc = E->build_frames(d_frames + (size_t)p.first_new * d_frame_stride, (long long)d_frame_stride,
@@ -381,17 +415,19 @@ int dfx_calc(dfx_handle h, const uint8_t *a, size_t a_pitch, const uint8_t *b, s
         return DFX_ERR_INVALID;
     if (!a || !b || !flow_uv)
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frame or flow pointer");
-    if (a_pitch < (size_t)h->W || b_pitch < (size_t)h->W)
+    const size_t rb = h->in_row_bytes();
+    const int rows = h->in_h();
+    if (a_pitch < rb || b_pitch < rb)
         return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
     if (a_pitch != b_pitch) { // dfx_calc_batch takes one pitch: repack both frames densely
-        std::vector<uint8_t> ta((size_t)h->W * h->H), tb((size_t)h->W * h->H);
-        for (int y = 0; y < h->H; ++y) {
-            std::memcpy(ta.data() + (size_t)y * h->W, a + (size_t)y * a_pitch, h->W);
-            std::memcpy(tb.data() + (size_t)y * h->W, b + (size_t)y * b_pitch, h->W);
+        std::vector<uint8_t> ta(rb * rows), tb(rb * rows);
+        for (int y = 0; y < rows; ++y) {
+            std::memcpy(ta.data() + (size_t)y * rb, a + (size_t)y * a_pitch, rb);
+            std::memcpy(tb.data() + (size_t)y * rb, b + (size_t)y * b_pitch, rb);
         }
         const uint8_t *fr[2] = {ta.data(), tb.data()};
         float *fl[1] = {flow_uv};
-        return dfx_calc_batch(h, fr, h->W, 2, 1, fl, out_pitch);
+        return dfx_calc_batch(h, fr, rb, 2, 1, fl, out_pitch);
     }
     const uint8_t *fr[2] = {a, b};
     float *fl[1] = {flow_uv};
@@ -405,7 +441,7 @@ int dfx_calc_batch(dfx_handle h, const uint8_t *const *frames, size_t frame_pitc
     const int M = std::max(n_frames - std::abs(step), 0);
     if (M > 0 && (!frames || !flows_uv))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or flows array");
-    if (M > 0 && (frame_pitch < (size_t)h->W || out_pitch < (size_t)h->W * 8))
+    if (M > 0 && (frame_pitch < h->in_row_bytes() || out_pitch < (size_t)h->W * 8))
         return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
     OutSpec out;
     out.flows = flows_uv;
@@ -420,7 +456,7 @@ int dfx_calc_batch_device(dfx_handle h, const uint8_t *d_frames, size_t pitch, s
     const int M = std::max(n_frames - std::abs(step), 0);
     if (M > 0 && (!d_frames || !d_flows))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL device frames or flows");
-    if (M > 0 && (pitch < (size_t)h->W || frame_stride < pitch * (size_t)h->H ||
+    if (M > 0 && (pitch < h->in_row_bytes() || frame_stride < pitch * (size_t)h->in_h() ||
                   flow_stride_floats < (size_t)h->W * h->H * 2))
         return dfx_fail(h, DFX_ERR_INVALID, "pitch/stride smaller than a frame");
     OutSpec out;
@@ -437,7 +473,7 @@ int dfx_calc_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame_p
     const int M = std::max(n_frames - std::abs(step), 0);
     if (M > 0 && (!frames || !img_x || !img_y))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or image plane array");
-    if (M > 0 && (frame_pitch < (size_t)h->W || img_pitch < (size_t)h->W))
+    if (M > 0 && (frame_pitch < h->in_row_bytes() || img_pitch < (size_t)h->W))
         return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
     OutSpec out;
     out.quantized = true;
@@ -457,7 +493,7 @@ int dfx_calc_batch_u8_device(dfx_handle h, const uint8_t *d_frames, size_t pitch
     const int M = std::max(n_frames - std::abs(step), 0);
     if (M > 0 && (!d_frames || !d_img_x || !d_img_y))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL device frames or image planes");
-    if (M > 0 && (pitch < (size_t)h->W || frame_stride < pitch * (size_t)h->H || img_pitch < (size_t)h->W ||
+    if (M > 0 && (pitch < h->in_row_bytes() || frame_stride < pitch * (size_t)h->in_h() || img_pitch < (size_t)h->W ||
                   img_stride < img_pitch * (size_t)h->H))
         return dfx_fail(h, DFX_ERR_INVALID, "pitch/stride smaller than a frame");
     OutSpec out;
@@ -493,6 +529,95 @@ int dfx_flow_to_u8_device(dfx_handle h, const float *d_flows, size_t flow_stride
     return DFX_OK;
 }
 
+int dfx_set_source_format(dfx_handle h, int src_width, int src_height, int channels) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    if (src_width == 0 && src_height == 0) { // back to the default: W x H gray frames
+        h->src_w = h->src_h = 0;
+        h->src_ch = 1;
+        return DFX_OK;
+    }
+    if (src_width < 1 || src_height < 1 || src_width > 32768 || src_height > 32768)
+        return dfx_fail(h, DFX_ERR_INVALID, "invalid source frame size");
+    if (channels != 1 && channels != 3)
+        return dfx_fail(h, DFX_ERR_INVALID, "channels must be 1 (gray) or 3 (BGR)");
+    if (src_width == h->W && src_height == h->H && channels == 1) {
+        h->src_w = h->src_h = 0;
+        h->src_ch = 1;
+        return DFX_OK;
+    }
+    h->src_w = src_width;
+    h->src_h = src_height;
+    h->src_ch = channels;
+    return DFX_OK;
+}
+
+int dfx_prepare_frames_device(dfx_handle h, const uint8_t *d_src, size_t src_pitch, size_t src_frame_stride,
+                              int src_width, int src_height, int channels, int n, uint8_t *d_gray, size_t gray_pitch,
+                              size_t gray_frame_stride) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    if (n < 0)
+        return dfx_fail(h, DFX_ERR_INVALID, "n must be >= 0");
+    if (n == 0)
+        return DFX_OK;
+    if (!d_src || !d_gray)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL device frames");
+    if (src_width < 1 || src_height < 1 || (channels != 1 && channels != 3))
+        return dfx_fail(h, DFX_ERR_INVALID, "invalid source format");
+    if (src_pitch < (size_t)src_width * channels || src_frame_stride < src_pitch * (size_t)src_height ||
+        gray_pitch < (size_t)h->W || gray_frame_stride < gray_pitch * (size_t)h->H)
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch/stride smaller than a frame");
+    HIPCHK(h, hipSetDevice(h->device));
+    prepare_launch(h->stream, d_src, (long long)src_pitch, (long long)src_frame_stride, src_width, src_height, channels,
+                   n, d_gray, (long long)gray_pitch, (long long)gray_frame_stride, h->W, h->H);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DFX_OK;
+}
+
+int dfx_prepare_frames(dfx_handle h, const uint8_t *const *src, size_t src_pitch, int src_width, int src_height,
+                       int channels, int n, uint8_t *const *gray, size_t gray_pitch) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    if (n < 0)
+        return dfx_fail(h, DFX_ERR_INVALID, "n must be >= 0");
+    if (n == 0)
+        return DFX_OK;
+    if (!src || !gray)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL frame arrays");
+    if (src_width < 1 || src_height < 1 || (channels != 1 && channels != 3))
+        return dfx_fail(h, DFX_ERR_INVALID, "invalid source format");
+    const size_t rb = (size_t)src_width * channels, fb = rb * src_height, plane = (size_t)h->W * h->H;
+    if (src_pitch < rb || gray_pitch < (size_t)h->W)
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned char *d_in = nullptr, *d_out = nullptr;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / std::max(fb, plane)));
+    auto run = [&]() -> int {
+        HIPCHK(h, hipMalloc(&d_in, (size_t)chunk * fb));
+        HIPCHK(h, hipMalloc(&d_out, (size_t)chunk * plane));
+        for (int i0 = 0; i0 < n; i0 += chunk) {
+            const int m = std::min(chunk, n - i0);
+            for (int j = 0; j < m; ++j)
+                HIPCHK(h, hipMemcpy2DAsync(d_in + (size_t)j * fb, rb, src[i0 + j], src_pitch, rb, src_height,
+                                           hipMemcpyHostToDevice, h->stream));
+            prepare_launch(h->stream, d_in, (long long)rb, (long long)fb, src_width, src_height, channels, m, d_out,
+                           h->W, (long long)plane, h->W, h->H);
+            HIPCHK(h, hipGetLastError());
+            for (int j = 0; j < m; ++j)
+                HIPCHK(h, hipMemcpy2DAsync(gray[i0 + j], gray_pitch, d_out + (size_t)j * plane, h->W, h->W, h->H,
+                                           hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        return DFX_OK;
+    };
+    const int rc = run();
+    dfx_free_dev(d_in);
+    dfx_free_dev(d_out);
+    return rc;
+}
+
 int dfx_get_stats(dfx_handle h, dfx_stats *out) {
     if (!h || !out)
         return DFX_ERR_INVALID;
@@ -523,6 +648,8 @@ void dfx_destroy(dfx_handle h) {
     for (auto &p : h->d_flow_out)
         dfx_free_dev(p);
     for (auto &p : h->d_img)
+        dfx_free_dev(p);
+    for (auto &p : h->d_src)
         dfx_free_dev(p);
     for (auto &e : h->ev_h2d)
         if (e)

@@ -39,6 +39,12 @@ struct dfx_context {
     int W = 0, H = 0;
     dfx_params prm{};
     std::string err;
+    // format of the frames handed to the calc entry points (dfx_set_source_format); 0 = the handle's own W x H gray
+    int src_w = 0, src_h = 0, src_ch = 1;
+    bool prepares() const { return src_w > 0; }
+    int in_w() const { return prepares() ? src_w : W; }   // width / height / bytes per row of an input frame
+    int in_h() const { return prepares() ? src_h : H; }
+    size_t in_row_bytes() const { return (size_t)in_w() * (prepares() ? src_ch : 1); }
 
     hipStream_t stream = nullptr;      // compute
     hipStream_t copy_stream = nullptr; // host <-> device copies of the host-pointer entry points
@@ -55,6 +61,9 @@ struct dfx_context {
     int u8_slots = 0;
     float *d_flow_out[2] = {nullptr, nullptr};   // flow_slots dense H*W*2 flows per set
     int flow_slots = 0;
+    unsigned char *d_src[2] = {nullptr, nullptr}; // source-format frames before preparation (src_slots per set)
+    int src_slots = 0;
+    size_t src_frame_bytes = 0;
     unsigned char *d_img[2] = {nullptr, nullptr}; // bounded output: img_slots x planes, then img_slots y planes
     int img_slots = 0;
     std::vector<int> h_slots;      // slot id of each new frame of the current batch

@@ -155,6 +155,12 @@ def load_library():
     L.dfx_calc_batch_u8_device.restype = i
     L.dfx_flow_to_u8_device.argtypes = [vp, vp, sz, i, C.c_double, C.c_double, vp, vp, sz, sz]
     L.dfx_flow_to_u8_device.restype = i
+    L.dfx_set_source_format.argtypes = [vp, i, i, i]
+    L.dfx_set_source_format.restype = i
+    L.dfx_prepare_frames.argtypes = [vp, C.POINTER(vp), sz, i, i, i, i, C.POINTER(vp), sz]
+    L.dfx_prepare_frames.restype = i
+    L.dfx_prepare_frames_device.argtypes = [vp, vp, sz, sz, i, i, i, i, vp, sz, sz]
+    L.dfx_prepare_frames_device.restype = i
     L.dfx_get_stats.argtypes = [vp, C.POINTER(DfxStats)]
     L.dfx_get_stats.restype = i
     L.dfx_reset_stats.argtypes = [vp]
@@ -243,12 +249,45 @@ class FlowEngine:
     def __exit__(self, *a):
         self.close()
 
+    # -- frame preparation on the device (reference: cvtColor + cv::resize in load_frames_batch) ----------
+    def set_source_format(self, src_width: int = 0, src_height: int = 0, channels: int = 1):
+        """Frames passed to calc / calc_optflows* are src_width x src_height with 1 (gray) or 3 (BGR) channels
+        from now on and are converted / resized to the engine's size on the device.  () restores the default."""
+        self._check(self._L.dfx_set_source_format(self._h, int(src_width), int(src_height), int(channels)))
+        self._src = (int(src_height), int(src_width)) + ((3,) if channels == 3 else ()) if src_width else None
+
+    def _frame_shape(self):
+        return getattr(self, "_src", None) or (self.height, self.width)
+
+    def prepare_frames(self, frames):
+        """cvtColor(BGR2GRAY) + cv::resize to the engine's size for a list of (h, w) or (h, w, 3) uint8 frames."""
+        src = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        n = len(src)
+        out = [np.empty((self.height, self.width), np.uint8) for _ in range(n)]
+        if n == 0:
+            return out
+        shp = src[0].shape
+        if any(f.shape != shp for f in src) or len(shp) not in (2, 3) or (len(shp) == 3 and shp[2] != 3):
+            raise ValueError("frames must share one (h, w) or (h, w, 3) shape")
+        ch = 1 if len(shp) == 2 else 3
+        sp = (C.c_void_p * n)(*[f.ctypes.data for f in src])
+        op = (C.c_void_p * n)(*[f.ctypes.data for f in out])
+        self._check(self._L.dfx_prepare_frames(self._h, sp, shp[1] * ch, shp[1], shp[0], ch, n, op, self.width))
+        return out
+
+    def prepare_frames_device(self, d_src_ptr: int, src_pitch: int, src_frame_stride: int, src_width: int,
+                              src_height: int, channels: int, n: int, d_gray_ptr: int, gray_pitch: int,
+                              gray_frame_stride: int):
+        self._check(self._L.dfx_prepare_frames_device(self._h, d_src_ptr, src_pitch, src_frame_stride, int(src_width),
+                                                      int(src_height), int(channels), int(n), d_gray_ptr, gray_pitch,
+                                                      gray_frame_stride))
+
     # -- the hot path ------------------------------------------------------------------------
     def calc(self, frame_a: np.ndarray, frame_b: np.ndarray) -> np.ndarray:
         """alg->calc(a, b): one (H, W, 2) float32 flow, channel 0 = u (x), 1 = v (y)."""
         a = np.ascontiguousarray(frame_a, dtype=np.uint8)
         b = np.ascontiguousarray(frame_b, dtype=np.uint8)
-        if a.shape != (self.height, self.width) or b.shape != a.shape:
+        if a.shape != self._frame_shape() or b.shape != a.shape:
             raise ValueError("frame shape does not match the engine")
         out = np.empty((self.height, self.width, 2), dtype=np.float32)
         self._check(self._L.dfx_calc(self._h, a.ctypes.data, a.strides[0], b.ctypes.data, b.strides[0],
@@ -264,11 +303,11 @@ class FlowEngine:
         if m == 0:
             return flows
         for f in frames:
-            if f.shape != (self.height, self.width):
+            if f.shape != self._frame_shape():
                 raise ValueError("frame shape does not match the engine")
         fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
         op = (C.c_void_p * m)(*[f.ctypes.data for f in flows])
-        self._check(self._L.dfx_calc_batch(self._h, fp, self.width, n, int(step), op, self.width * 8))
+        self._check(self._L.dfx_calc_batch(self._h, fp, frames[0].strides[0], n, int(step), op, self.width * 8))
         return flows
 
     def calc_optflows_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,
@@ -291,14 +330,14 @@ class FlowEngine:
         if m == 0:
             return img_x, img_y
         for f in frames:
-            if f.shape != (self.height, self.width):
+            if f.shape != self._frame_shape():
                 raise ValueError("frame shape does not match the engine")
         lo = -float(bound) if lower is None else float(lower)
         fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
         xp = (C.c_void_p * m)(*[f.ctypes.data for f in img_x])
         yp = (C.c_void_p * m)(*[f.ctypes.data for f in img_y])
-        self._check(self._L.dfx_calc_batch_u8(self._h, fp, self.width, n, int(step), lo, float(bound), xp, yp,
-                                              self.width))
+        self._check(self._L.dfx_calc_batch_u8(self._h, fp, frames[0].strides[0], n, int(step), lo, float(bound), xp,
+                                              yp, self.width))
         return img_x, img_y
 
     def calc_optflows_u8_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,

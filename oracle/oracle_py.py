@@ -107,6 +107,10 @@ def lib():
         L.orc_brox_calc.restype = C.c_int
         L.orc_brox_pyramid_sizes.argtypes = [C.c_int, C.c_int, C.POINTER(BroxParams), C.POINTER(C.c_int), C.c_int]
         L.orc_brox_pyramid_sizes.restype = C.c_int
+    if hasattr(L, "orc_prepare_frame"):
+        L.orc_prepare_frame.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
+        L.orc_resize_u8.argtypes = [_u8p, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
+        L.orc_bgr2gray.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
     if hasattr(L, "orc_flow_to_u8"):
         L.orc_flow_to_u8.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p]
     _lib = L
@@ -263,3 +267,15 @@ def ref_flow_to_u8(flow: np.ndarray, lower: float, upper: float):
     img_y = np.empty((h, w), np.uint8)
     _ref_quant.ref_convert_flow_to_image(fx, fy, w, h, float(lower), float(upper), img_x, img_y)
     return img_x, img_y
+
+
+# ---------------------------------------------------------------------------------------------- frame preparation
+def prepare_frame(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    """The loader's cvtColor(BGR2GRAY) + cv::resize (reference src/denseflow_gpu.cpp:163, :169) for one frame:
+    src (H, W) gray or (H, W, 3) BGR uint8 -> (dh, dw) uint8."""
+    src = np.ascontiguousarray(src, dtype=np.uint8)
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    sh, sw = src.shape[:2]
+    dst = np.empty((dh, dw), np.uint8)
+    lib().orc_prepare_frame(src.reshape(-1), sw, sh, ch, dst, dw, dh)
+    return dst
