@@ -30,9 +30,13 @@ class FlowBuffer {
     // Extension: flows already bounded to 8 bits on the device.  item_data then holds 2M CV_8UC1 planes,
     // x and y alternating (flow i = item_data[2i], item_data[2i+1]), instead of M CV_32FC2 fields.
     bool bounded;
-    FlowBuffer(vector<Mat> item_data, path output_dir, int base_start, bool last_buffer, bool bounded = false)
+    // Extension: frames that still have the source size; the flow stage resizes them to `target` on the device
+    // (width 0: the frames already have their final size).
+    Size target;
+    FlowBuffer(vector<Mat> item_data, path output_dir, int base_start, bool last_buffer, bool bounded = false,
+               Size target = Size())
         : item_data(std::move(item_data)), output_dir(std::move(output_dir)), base_start(base_start),
-          last_buffer(last_buffer), bounded(bounded) {}
+          last_buffer(last_buffer), bounded(bounded), target(target) {}
 };
 
 // Bounded producer/consumer queue (the reference hand-rolls two of these with a mutex and two
@@ -74,6 +78,10 @@ class DenseFlow {
     // inside encode_save (the reference encodes on one thread); DF_ENCODE_THREADS overrides.
     bool device_bounding;
     int encode_threads;
+    // Extension of the load stage: a requested resize (-nw/-nh/-ns) is done by the flow stage
+    // on the GPU (dfx_set_source_format) instead of cv::resize on the loader thread; DF_HOST_RESIZE=1 restores
+    // the host-side resize (same integer arithmetic, same output).
+    bool device_resize;
 
     int batch_maxsize;
     FlowBufferQueue frames_gray_queue;

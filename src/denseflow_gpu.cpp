@@ -73,6 +73,7 @@ DenseFlow::DenseFlow(vector<path> video_paths, vector<path> output_dirs, string 
       new_short(new_short), has_class(has_class), is_record(is_record), device(device), batch_maxsize(512),
       frames_gray_queue(3), flows_queue(3), total_frames(0), total_flows(0), dfx_(nullptr) {
     device_bounding = this->save_type == "jpg" && !std::getenv("DF_HOST_BOUND");
+    device_resize = !std::getenv("DF_HOST_RESIZE");
     const char *et = std::getenv("DF_ENCODE_THREADS");
     const int hw = (int)std::thread::hardware_concurrency();
     encode_threads = et ? std::max(1, std::atoi(et)) : std::max(1, std::min(hw > 0 ? hw : 1, 32));
@@ -169,7 +170,7 @@ static vector<path> list_frames(const path &dir) {
 
 bool DenseFlow::load_frames_batch(VideoCapture &video_stream, const vector<path> &frames_path, bool use_frames,
                                   vector<Mat> &frames_gray, bool do_resize, const Size &size, bool to_gray) {
-    (void)to_gray; // sources are gray already (Y plane / PGM / BGR2GRAY in imreadGray)
+    // to_gray: the flow pipeline (sources are gray already: Y plane / PGM / BGR2GRAY in imreadGray); false: -s=0
     int cnt = 0;
     while (cnt < batch_maxsize) {
         Mat frame;
@@ -181,7 +182,7 @@ bool DenseFlow::load_frames_batch(VideoCapture &video_stream, const vector<path>
         } else if (!video_stream.read(frame)) {
             return false;
         }
-        if (do_resize) {
+        if (do_resize && !(to_gray && device_resize)) { // flow pipeline: the GPU resizes (calc_optflows_imp)
             Mat resized;
             resizeLinear(frame, resized, size);
             frames_gray.push_back(resized);
@@ -208,7 +209,9 @@ int DenseFlow::load_frames_video(VideoCapture &video_stream, vector<path> &frame
                  << endl;
         TRACE("load: push %zu frames, base %d, last_buffer %d, final %d", padded.size(), video_flow_idx, (int)!is_open,
               (int)(is_last && !is_open));
-        frames_gray_queue.push(FlowBuffer(padded, output_dir, video_flow_idx, !is_open), is_last && !is_open);
+        frames_gray_queue.push(FlowBuffer(padded, output_dir, video_flow_idx, !is_open, false,
+                                          (do_resize && device_resize) ? size : Size()),
+                               is_last && !is_open);
         // the last |step| frames are needed again as the head of the next buffer (:204-207)
         padding.assign(padded.end() - std::min<size_t>(astep, padded.size()), padded.end());
         const int M = (int)padded.size() - astep;
@@ -250,7 +253,9 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
         // overlap across buffers, so large frames get shorter buffers (>= 2 device batches each): 64 frames at
         // 1080p, 512 from 512x512 down.  Buffer boundaries do not change any flow (the last |step| frames
         // are carried over, :204-207).
-        batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, (128ll << 20) / std::max(1ll, (long long)size.width * size.height)));
+        const long long frame_px = std::max((long long)size.width * size.height,
+                                            use_frames ? 0ll : (long long)video_stream.width() * video_stream.height());
+        batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, (128ll << 20) / std::max(1ll, frame_px)));
         if (const char *bm = std::getenv("DF_BATCH_MAXSIZE")) // testing aid: force short buffers
             batch_maxsize = std::max(1, std::atoi(bm));
         if (verbose)
@@ -284,7 +289,8 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
             char msg[256];
             throw std::runtime_error(dfx_algo_error_message(rc, algorithm.c_str(), msg, sizeof msg));
         }
-        const Size sz = frames_gray.item_data[0].size();
+        const Size in_sz = frames_gray.item_data[0].size();
+        const Size sz = frames_gray.target.width > 0 ? frames_gray.target : in_sz; // size of the flows
         TRACE("calc: %d frames -> %d flows, %dx%d, algorithm %s", N, M, sz.width, sz.height, algorithm.c_str());
         if (!dfx_ || !(sz == dfx_size_)) { // sized per video; reused across its FlowBuffers
             if (dfx_)
@@ -294,6 +300,9 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
                 throw std::runtime_error(dfx_last_error(nullptr));
             dfx_size_ = sz;
         }
+        // cv::resize of load_frames_batch (:169) on the device: source-size frames go up, the engine resizes
+        if (dfx_set_source_format(dfx_, sz == in_sz ? 0 : in_sz.width, sz == in_sz ? 0 : in_sz.height, 1) != DFX_OK)
+            throw std::runtime_error(dfx_last_error(dfx_));
         vector<const uint8_t *> in(N);
         for (int i = 0; i < N; ++i)
             in[i] = frames_gray.item_data[i].ptr<uint8_t>();

@@ -113,30 +113,59 @@ bool imreadGray(const string &file, Mat &gray) {
     if (fread(rgb.data(), 1, rgb.size(), fp) != rgb.size())
         return false;
     uchar *g = gray.data();
-    for (size_t i = 0; i < (size_t)w * h; ++i) // cvtColor BGR2GRAY fixed-point weights (R 4899, G 9617, B 1868, >> 14)
-        g[i] = (uchar)((rgb[3 * i] * 4899 + rgb[3 * i + 1] * 9617 + rgb[3 * i + 2] * 1868 + 8192) >> 14);
+    for (size_t i = 0; i < (size_t)w * h; ++i) // cvtColor BGR2GRAY, 8-bit: 15-bit weights R 9798, G 19235, B 3735
+        g[i] = (uchar)((rgb[3 * i] * 9798 + rgb[3 * i + 1] * 19235 + rgb[3 * i + 2] * 3735 + (1 << 14)) >> 15);
     return true;
 }
 
+// cv::resize(src, dst, size) for CV_8UC1 with the default INTER_LINEAR, in OpenCV's 8-bit integer arithmetic
+// (the same arithmetic as the device path, denseflow_amd/csrc/prepare_kernels.hip): source coordinate
+// (float)((d + 0.5)*scale - 0.5); 11-bit fixed-point weights; along x an out-of-range index is clamped and its
+// fraction zeroed, along y the two row indices are clamped; an exact 2x2 decimation is a rounded 2x2 mean
+// (cv::resize executes that INTER_LINEAR request as INTER_AREA).
 void resizeLinear(const Mat &src, Mat &dst, Size size) {
     dst.create(size, CV_8UC1);
-    const double fx = (double)src.cols / size.width, fy = (double)src.rows / size.height;
-    for (int y = 0; y < size.height; ++y) {
-        double sy = (y + 0.5) * fy - 0.5;
-        int y0 = (int)std::floor(sy);
-        double wy = sy - y0;
-        int y1 = std::min(std::max(y0 + 1, 0), src.rows - 1);
-        y0 = std::min(std::max(y0, 0), src.rows - 1);
-        const uchar *r0 = src.ptr<uchar>(y0), *r1 = src.ptr<uchar>(y1);
+    const int sw = src.cols, sh = src.rows, dw = size.width, dh = size.height;
+    if (sw == dw && sh == dh) {
+        for (int y = 0; y < dh; ++y)
+            std::memcpy(dst.ptr<uchar>(y), src.ptr<uchar>(y), dw);
+        return;
+    }
+    if (sw == 2 * dw && sh == 2 * dh) {
+        for (int y = 0; y < dh; ++y) {
+            const uchar *r0 = src.ptr<uchar>(2 * y), *r1 = src.ptr<uchar>(2 * y + 1);
+            uchar *d = dst.ptr<uchar>(y);
+            for (int x = 0; x < dw; ++x)
+                d[x] = (uchar)((r0[2 * x] + r0[2 * x + 1] + r1[2 * x] + r1[2 * x + 1] + 2) >> 2);
+        }
+        return;
+    }
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    vector<int> xo(dw), a0(dw), a1(dw);
+    for (int x = 0; x < dw; ++x) {
+        float f = (float)((x + 0.5) * scale_x - 0.5);
+        int s = (int)std::floor(f);
+        f -= (float)s;
+        if (s < 0)
+            f = 0.f, s = 0;
+        if (s >= sw - 1)
+            f = 0.f, s = sw - 1;
+        xo[x] = s;
+        a0[x] = (int)std::lrintf((1.f - f) * 2048.f);
+        a1[x] = (int)std::lrintf(f * 2048.f);
+    }
+    for (int y = 0; y < dh; ++y) {
+        float f = (float)((y + 0.5) * scale_y - 0.5);
+        const int s = (int)std::floor(f);
+        f -= (float)s;
+        const int b0 = (int)std::lrintf((1.f - f) * 2048.f), b1 = (int)std::lrintf(f * 2048.f);
+        const uchar *r0 = src.ptr<uchar>(std::min(std::max(s, 0), sh - 1));
+        const uchar *r1 = src.ptr<uchar>(std::min(std::max(s + 1, 0), sh - 1));
         uchar *d = dst.ptr<uchar>(y);
-        for (int x = 0; x < size.width; ++x) {
-            double sx = (x + 0.5) * fx - 0.5;
-            int x0 = (int)std::floor(sx);
-            double wx = sx - x0;
-            int x1 = std::min(std::max(x0 + 1, 0), src.cols - 1);
-            x0 = std::min(std::max(x0, 0), src.cols - 1);
-            const double v = (1 - wy) * ((1 - wx) * r0[x0] + wx * r0[x1]) + wy * ((1 - wx) * r1[x0] + wx * r1[x1]);
-            d[x] = (uchar)std::min(255.0, std::max(0.0, std::nearbyint(v)));
+        for (int x = 0; x < dw; ++x) {
+            const int x0 = xo[x], x1 = std::min(x0 + 1, sw - 1);
+            const int h0 = r0[x0] * a0[x] + r0[x1] * a1[x], h1 = r1[x0] * a0[x] + r1[x1] * a1[x];
+            d[x] = (uchar)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
         }
     }
 }

@@ -7,6 +7,14 @@
 
 extern "C" {
 
+// resizeLinear (the host-side cv::resize stand-in) on a dense gray frame
+void hh_resize(const uchar *src, int sw, int sh, uchar *dst, int dw, int dh) {
+    Mat a(Size(sw, sh), CV_8UC1), b;
+    memcpy(a.data(), src, (size_t)sw * sh);
+    resizeLinear(a, b, Size(dw, dh));
+    memcpy(dst, b.data(), (size_t)dw * dh);
+}
+
 void hh_jpeg_force_portable(int on) { imencodeJpegForcePortable(on != 0); }
 
 int hh_encode_jpeg(const uchar *gray, int w, int h, int quality, uchar *out, int out_cap) {

@@ -211,6 +211,15 @@ def test_operator_matches_oracle_on_gpu(harness, oracle):
     assert m == -1 and err.value == b"NV hardware flow not enabled, pls recompile"
 
 
+@pytest.mark.parametrize("sw,sh,dw,dh", [(64, 48, 32, 24), (340, 256, 224, 224), (100, 70, 224, 224), (33, 17, 64, 64),
+                                         (640, 360, 455, 256), (7, 5, 3, 2), (64, 48, 64, 48)])
+def test_host_resize_is_the_oracles_cv_resize(harness, oracle, sw, sh, dw, dh):
+    src = np.random.default_rng(sw + dh).integers(0, 256, (sh, sw), dtype=np.uint8)
+    dst = np.zeros((dh, dw), np.uint8)
+    harness.hh_resize(src.ctypes.data_as(C.c_void_p), sw, sh, dst.ctypes.data_as(C.c_void_p), dw, dh)
+    assert np.array_equal(dst, oracle.prepare_frame(src, dw, dh))
+
+
 def test_parallel_for_covers_every_index_and_propagates_errors(harness):
     harness.hh_parallel_sum.restype = C.c_long
     for n, threads in [(0, 4), (1, 8), (100, 1), (1000, 7), (5, 64)]:
@@ -293,6 +302,33 @@ def test_buffer_boundaries_do_not_change_the_output(built, tmp_path, source, ste
         outs[tag] = {p.name: p.read_bytes() for p in sorted(d.iterdir())}
     assert len(outs["one"]) == 2 * (n - step)
     assert outs["cut"] == outs["one"] and outs["cut3"] == outs["one"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resize_args", [["-nw=96", "-nh=72"], ["-ns=60"], ["-nw=100"]])
+def test_cli_device_resize_writes_the_same_files_as_host_resize(built, tmp_path, resize_args):
+    """-nw/-nh/-ns: by default the loader hands source-size frames to the GPU, which resizes them (dfx_set_source_format);
+    DF_HOST_RESIZE=1 resizes on the loader thread like the reference.  Same arithmetic, so identical files."""
+    w, h, n = 192, 144, 7
+    frames = SynthClip(w, h, 6).frames(n)
+    clip = tmp_path / "clip.y4m"
+    write_y4m(clip, frames)
+    lst = tmp_path / "list.txt"
+    lst.write_text(str(clip) + "\n")
+    outs = {}
+    for tag, env in (("dev", {}), ("host", {"DF_HOST_RESIZE": "1"})):
+        r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / tag), "-a=tvl1", "-s=1", "-b=20"] + resize_args,
+                           capture_output=True, text=True, env={**os.environ, "DF_BATCH_MAXSIZE": "4", **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+        d = tmp_path / tag / "clip"
+        outs[tag] = {p.name: p.read_bytes() for p in sorted(d.iterdir())}
+    assert len(outs["dev"]) == 2 * (n - 1)
+    assert outs["dev"] == outs["host"]
+    from PIL import Image
+
+    img = Image.open(tmp_path / "dev" / "clip" / "flow_x_00000.jpg")
+    expect = {"-nw=96": (96, 72), "-ns=60": (80, 60), "-nw=100": (100, 75)}[resize_args[0]]
+    assert img.size == expect
 
 
 @pytest.mark.gpu
