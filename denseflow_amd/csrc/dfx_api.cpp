@@ -111,6 +111,16 @@ struct OutSpec {
     size_t d_img_stride = 0;
 };
 
+// One frame / plane between host and device.  Dense rows (pitch == row bytes on both sides) go as ONE linear copy:
+// a 2-D copy of a small frame costs several times the linear one, and a FlowBuffer of 224x224 frames is hundreds
+// of them.
+inline hipError_t copy_rows_async(void *dst, size_t dpitch, const void *src, size_t spitch, size_t row_bytes,
+                                  size_t rows, hipMemcpyKind kind, hipStream_t s) {
+    if (dpitch == row_bytes && spitch == row_bytes)
+        return hipMemcpyAsync(dst, src, row_bytes * rows, kind, s);
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, kind, s);
+}
+
 struct BatchPlan {
     int i0, nb;          // pairs [i0, i0+nb)
     long long first_new; // first frame id that has to be prepared for this batch
@@ -180,8 +190,8 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         const size_t rb = c->in_row_bytes(), fb = rb * c->in_h();
         unsigned char *dst = prep ? c->d_src[k & 1] : c->d_u8[k & 1];
         for (int j = 0; j < p.n_new; ++j)
-            HIPCHK(c, hipMemcpy2DAsync(dst + (size_t)j * fb, rb, frames[p.first_new + j], frame_pitch, rb, c->in_h(),
-                                       hipMemcpyHostToDevice, c->copy_stream));
+            HIPCHK(c, copy_rows_async(dst + (size_t)j * fb, rb, frames[p.first_new + j], frame_pitch, rb, c->in_h(),
+                                      hipMemcpyHostToDevice, c->copy_stream));
         HIPCHK(c, hipEventRecord(c->ev_h2d[k & 1], c->copy_stream));
         return DFX_OK;
     };
@@ -192,14 +202,14 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             if (out.quantized) {
                 const unsigned char *sx = c->d_img[k & 1] + (size_t)j * plane;
                 const unsigned char *sy = c->d_img[k & 1] + ((size_t)c->img_slots + j) * plane;
-                HIPCHK(c, hipMemcpy2DAsync(out.img_x[p.i0 + j], out.img_pitch, sx, c->W, c->W, c->H,
-                                           hipMemcpyDeviceToHost, c->copy_stream));
-                HIPCHK(c, hipMemcpy2DAsync(out.img_y[p.i0 + j], out.img_pitch, sy, c->W, c->W, c->H,
-                                           hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, copy_rows_async(out.img_x[p.i0 + j], out.img_pitch, sx, c->W, c->W, c->H,
+                                          hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, copy_rows_async(out.img_y[p.i0 + j], out.img_pitch, sy, c->W, c->W, c->H,
+                                          hipMemcpyDeviceToHost, c->copy_stream));
             } else {
-                HIPCHK(c, hipMemcpy2DAsync(out.flows[p.i0 + j], out.out_pitch, c->d_flow_out[k & 1] + (size_t)j * plane * 2,
-                                           (size_t)c->W * 8, (size_t)c->W * 8, c->H, hipMemcpyDeviceToHost,
-                                           c->copy_stream));
+                HIPCHK(c, copy_rows_async(out.flows[p.i0 + j], out.out_pitch, c->d_flow_out[k & 1] + (size_t)j * plane * 2,
+                                          (size_t)c->W * 8, (size_t)c->W * 8, c->H, hipMemcpyDeviceToHost,
+                                          c->copy_stream));
             }
         }
         HIPCHK(c, hipEventRecord(c->ev_d2h[k & 1], c->copy_stream));
