@@ -184,9 +184,9 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
                     brox_launch_sor(c->stream, x, uv, ds, 1);
                 }
             } else {
-                const int S = brox_fused_sweeps();
+                const int S = brox_fused_sweeps(p.tvl1_tile_h);
                 for (int si = 0; si < p.brox_solver_iterations; si += S) {
-                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si));
+                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si), p.tvl1_tile_h);
                     ds ^= 1; // it wrote the other set
                 }
             }
@@ -194,7 +194,7 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
         brox_launch_add_increment(c->stream, x, uv, ds);
         batch_launches += 2 + (uint64_t)p.brox_inner_iterations *
                                   (2 + (p.impl == 1 ? 2 * p.brox_solver_iterations
-                                                    : (p.brox_solver_iterations + brox_fused_sweeps() - 1) / brox_fused_sweeps()));
+                                                    : (p.brox_solver_iterations + brox_fused_sweeps(p.tvl1_tile_h) - 1) / brox_fused_sweeps(p.tvl1_tile_h)));
         if (l > 0) {
             brox_launch_prolongate(c->stream, x, uv, lv[l - 1].w, lv[l - 1].h, lv[l - 1].pitch, p.brox_scale_factor,
                                    1.0f / p.brox_scale_factor);

@@ -247,27 +247,26 @@ __global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, in
     DV[o] = dv_n;
 }
 
-// Fused SOR: up to BROX_FUSE_SWEEPS full red+black sweeps per launch on a 128 x 32 tile (1024 threads,
-// each owning a 2-column x 2-row patch: 14 values x 4 pixels stay under 128 VGPRs, 16 waves per CU).  The 9 per-pixel coefficients and u, v stay in registers, only
+// Fused SOR: several full red+black sweeps per launch on an LDS tile; each thread owns a 2-column x 2-row patch
+// (14 values x 4 pixels stay under 128 VGPRs).  The 9 per-pixel coefficients and u, v stay in registers, only
 // w = u + du (the quantity neighbours read) lives in LDS.  Tile origins are even, so a pixel's colour is a
 // compile-time function of its position in the patch.  Every half-sweep shrinks the valid region by one
 // pixel; a halo of 2 pixels per sweep is recomputed redundantly and only the inner region is written
 // back.  Same per-pixel expression, same order: bit-identical to the one-launch-per-half-sweep form.
-#define BROX_FUSE_SWEEPS 2
-#define BROX_TW 128
-#define BROX_TH 32
-#define BROX_HALO (2 * BROX_FUSE_SWEEPS)
-
 #define BROX_PR 2 // patch rows per thread
-__global__ __launch_bounds__(1024) void k_brox_sor_fused(BroxLevelCtx c, int uv_set, int d_src, int n_sweeps, int tiles_x) {
+// Tile BROX_TW x BROX_TH (one thread per 2x2 patch), up to BROX_S sweeps per launch (halo 2*BROX_S).
+template <int BROX_TW, int BROX_TH, int BROX_S>
+__global__ __launch_bounds__(BROX_TW *BROX_TH / 4) void k_brox_sor_fused(BroxLevelCtx c, int uv_set, int d_src,
+                                                                         int n_sweeps, int tiles_x) {
+    constexpr int BROX_HALO = 2 * BROX_S;
     __shared__ float WU[BROX_TH][BROX_TW];
     __shared__ float WV[BROX_TH][BROX_TW];
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
     const int x0 = tx * (BROX_TW - 2 * BROX_HALO) - BROX_HALO; // even
     const int y0 = ty * (BROX_TH - 2 * BROX_HALO) - BROX_HALO; // even
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lx0 = 2 * lane, ly0 = BROX_PR * wave;
+    const int pcol = threadIdx.x % (BROX_TW / 2), prow = threadIdx.x / (BROX_TW / 2);
+    const int lx0 = 2 * pcol, ly0 = BROX_PR * prow;
 
     const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
     const float *DU = bplane(c, b, du_plane(d_src)), *DV = bplane(c, b, dv_plane(d_src));
@@ -437,13 +436,43 @@ void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c) {
 void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set, int color) {
     hipLaunchKernelGGL(k_brox_sor, bgrid((c.w + 1) / 2, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set, color);
 }
-void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps) {
-    const int tiles_x = (c.w + (BROX_TW - 2 * BROX_HALO) - 1) / (BROX_TW - 2 * BROX_HALO);
-    const int tiles_y = (c.h + (BROX_TH - 2 * BROX_HALO) - 1) / (BROX_TH - 2 * BROX_HALO);
-    hipLaunchKernelGGL(k_brox_sor_fused, dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(1024), 0, s, c, uv_set, d_src, n_sweeps,
-                       tiles_x);
+// cfg (dfx_params.tvl1_tile_h doubles as the knob): 0 / 645 = 64x64 tile, 5 sweeps per launch (default: the
+// reference's 10 solver iterations are two launches; measured 164 pairs/s at 1080p against 138 for 64x32 / 2 sweeps and
+// 133 for 128x32 / 2); 64 = 64x32, 2 sweeps; 128 = 128x32, 2; 642 / 643 = 64x64 with 2 / 3.
+static void sor_cfg(int cfg, int &tw, int &th, int &S) {
+    tw = 64, th = 64, S = 5;
+    if (cfg == 128)
+        tw = 128, th = 32, S = 2;
+    else if (cfg == 64)
+        th = 32, S = 2;
+    else if (cfg == 642 || cfg == 643)
+        S = cfg - 640;
 }
-int brox_fused_sweeps(void) { return BROX_FUSE_SWEEPS; }
+template <int TW, int TH, int S>
+static void sor_launch(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps) {
+    const int tiles_x = (c.w + (TW - 4 * S) - 1) / (TW - 4 * S), tiles_y = (c.h + (TH - 4 * S) - 1) / (TH - 4 * S);
+    hipLaunchKernelGGL((k_brox_sor_fused<TW, TH, S>), dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(TW * TH / 4), 0, s, c,
+                       uv_set, d_src, n_sweeps, tiles_x);
+}
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int cfg) {
+    int tw, th, S;
+    sor_cfg(cfg, tw, th, S);
+    if (tw == 128)
+        sor_launch<128, 32, 2>(s, c, uv_set, d_src, n_sweeps);
+    else if (th == 32)
+        sor_launch<64, 32, 2>(s, c, uv_set, d_src, n_sweeps);
+    else if (S == 2)
+        sor_launch<64, 64, 2>(s, c, uv_set, d_src, n_sweeps);
+    else if (S == 3)
+        sor_launch<64, 64, 3>(s, c, uv_set, d_src, n_sweeps);
+    else
+        sor_launch<64, 64, 5>(s, c, uv_set, d_src, n_sweeps);
+}
+int brox_fused_sweeps(int cfg) {
+    int tw, th, S;
+    sor_cfg(cfg, tw, th, S);
+    return S;
+}
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set) {
     hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set);
 }
