@@ -177,8 +177,8 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
         int ds = 0; // du/dv set holding the current increment
         for (int in = 0; in < p.brox_inner_iterations; ++in) {
             brox_launch_stage1(c->stream, x, uv, ds);
-            brox_launch_stage2(c->stream, x);
-            if (p.impl == 1) { // simple form: one launch per half sweep, in place
+            if (p.impl == 1) { // simple form: stage 2 as its own launch, then one launch per half sweep, in place
+                brox_launch_stage2(c->stream, x);
                 for (int si = 0; si < p.brox_solver_iterations; ++si) {
                     brox_launch_sor(c->stream, x, uv, ds, 0);
                     brox_launch_sor(c->stream, x, uv, ds, 1);
@@ -193,7 +193,7 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
         }
         brox_launch_add_increment(c->stream, x, uv, ds);
         batch_launches += 2 + (uint64_t)p.brox_inner_iterations *
-                                  (2 + (p.impl == 1 ? 2 * p.brox_solver_iterations
+                                  (1 + (p.impl == 1 ? 1 + 2 * p.brox_solver_iterations
                                                     : (p.brox_solver_iterations + brox_fused_sweeps(p.tvl1_tile_h) - 1) / brox_fused_sweeps(p.tvl1_tile_h)));
         if (l > 0) {
             brox_launch_prolongate(c->stream, x, uv, lv[l - 1].w, lv[l - 1].h, lv[l - 1].pitch, p.brox_scale_factor,

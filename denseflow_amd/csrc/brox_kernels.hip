@@ -142,20 +142,32 @@ __device__ __forceinline__ float bl_sample(const float *p, const BlTap &t) {
     return (1.0f - t.ay) * a + t.ay * b;
 }
 
-// stage 1: data-term coefficients and staggered diffusivities (brox_oracle.h, step 3b)
+// stage 1: data-term coefficients and staggered diffusivities (brox_oracle.h, step 3b).
+// The diffusivities read w = u + du and v + dv at 14 neighbour positions per pixel; the workgroup builds both
+// sums once for its 64 x 4 pixels plus a 1-pixel ring (coordinates clamped to the image, which is exactly the
+// max(x-1, 0) / min(x+1, w-1) addressing of the definition) in LDS instead of 56 global loads per pixel.
 __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set, int d_set) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= c.w || y >= c.h)
-        return;
+    __shared__ float WUs[6][68], WVs[6][68];
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = x0 + lx, y = y0 + ly;
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
-    const PairDesc pd = c.pairs[b];
     const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
     const float *DU = bplane(c, b, du_plane(d_set)), *DV = bplane(c, b, dv_plane(d_set));
+    for (int e = threadIdx.x; e < 6 * 66; e += 256) {
+        const int ty = e / 66, tx = e - ty * 66;
+        const long long so = (long long)min(max(y0 - 1 + ty, 0), h - 1) * pitch + min(max(x0 - 1 + tx, 0), w - 1);
+        WUs[ty][tx] = u[so] + DU[so];
+        WVs[ty][tx] = v[so] + DV[so];
+    }
+    __syncthreads();
+    if (x >= w || y >= h)
+        return;
+    const PairDesc pd = c.pairs[b];
     const long long o = (long long)y * pitch + x;
-    const int xm = max(x - 1, 0), xp = min(x + 1, w - 1), ym = max(y - 1, 0), yp = min(y + 1, h - 1);
-#define WU(xx, yy) (u[(long long)(yy)*pitch + (xx)] + DU[(long long)(yy)*pitch + (xx)])
-#define WV(xx, yy) (v[(long long)(yy)*pitch + (xx)] + DV[(long long)(yy)*pitch + (xx)])
+    // tile coordinates of (x, y) are (lx + 1, ly + 1); m / p = the clamped neighbours
+#define WU(dx, dy) WUs[ly + 1 + (dy)][lx + 1 + (dx)]
+#define WV(dx, dy) WVs[ly + 1 + (dy)][lx + 1 + (dx)]
     const BlTap t = bl_setup((float)x + u[o], (float)y + v[o], w, h, pitch);
     const float I1w = bl_sample(fplane(c, pd.frame_b, BROX_FP_I), t);
     const float Ixw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DX), t);
@@ -179,15 +191,15 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set,
     bplane(c, b, BROX_PL_NV)[o] = psi * (Iyw * Iz + gamma * (Iyyw * Iyz + Ixyw * Ixz));
     float gx = 0.0f, gy = 0.0f;
     if (x > 0) {
-        const float ux = WU(x, y) - WU(xm, y), vx = WV(x, y) - WV(xm, y);
-        const float uy = 0.25f * (((WU(x, yp) + WU(xm, yp)) - WU(x, ym)) - WU(xm, ym));
-        const float vy = 0.25f * (((WV(x, yp) + WV(xm, yp)) - WV(x, ym)) - WV(xm, ym));
+        const float ux = WU(0, 0) - WU(-1, 0), vx = WV(0, 0) - WV(-1, 0);
+        const float uy = 0.25f * (((WU(0, 1) + WU(-1, 1)) - WU(0, -1)) - WU(-1, -1));
+        const float vy = 0.25f * (((WV(0, 1) + WV(-1, 1)) - WV(0, -1)) - WV(-1, -1));
         gx = 0.5f * inv_sqrtf_ieee((((ux * ux + uy * uy) + vx * vx) + vy * vy) + BROX_EPS2);
     }
     if (y > 0) {
-        const float uy = WU(x, y) - WU(x, ym), vy = WV(x, y) - WV(x, ym);
-        const float ux = 0.25f * (((WU(xp, y) + WU(xp, ym)) - WU(xm, y)) - WU(xm, ym));
-        const float vx = 0.25f * (((WV(xp, y) + WV(xp, ym)) - WV(xm, y)) - WV(xm, ym));
+        const float uy = WU(0, 0) - WU(0, -1), vy = WV(0, 0) - WV(0, -1);
+        const float ux = 0.25f * (((WU(1, 0) + WU(1, -1)) - WU(-1, 0)) - WU(-1, -1));
+        const float vx = 0.25f * (((WV(1, 0) + WV(1, -1)) - WV(-1, 0)) - WV(-1, -1));
         gy = 0.5f * inv_sqrtf_ieee((((ux * ux + uy * uy) + vx * vx) + vy * vy) + BROX_EPS2);
     }
     bplane(c, b, BROX_PL_GX)[o] = gx;
@@ -289,8 +301,10 @@ __global__ __launch_bounds__(BROX_TW *BROX_TH / 4) void k_brox_sor_fused(BroxLev
             gd[i][k] = in ? GY[o] : 0.0f;
             gu[i][k] = (in && y + 1 < h) ? GY[o + pitch] : 0.0f;
             gs[i][k] = ((gl[i][k] + gr[i][k]) + gd[i][k]) + gu[i][k];
-            idu[i][k] = in ? IDU[o] : 0.0f;
-            idv[i][k] = in ? IDV[o] : 0.0f;
+            // stage 2 of the definition, 1 / (data term + sum of diffusivities), evaluated here from the raw planes:
+            // the fused path never launches k_brox_stage2 (same expression, same bits)
+            idu[i][k] = in ? 1.0f / (IDU[o] + gs[i][k]) : 0.0f;
+            idv[i][k] = in ? 1.0f / (IDV[o] + gs[i][k]) : 0.0f;
             nd[i][k] = in ? NDUDV[o] : 0.0f;
             nu[i][k] = in ? NU[o] : 0.0f;
             nv[i][k] = in ? NV[o] : 0.0f;
