@@ -75,6 +75,26 @@ int ensure_src_staging(dfx_context *c, int need) {
     return DFX_OK;
 }
 
+int ensure_bounce(dfx_context *c, size_t in_bytes, size_t out_bytes) {
+    if (in_bytes > c->h_in_bytes) {
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto &p : c->h_in) {
+            dfx_free_host(p);
+            HIPCHK(c, hipHostMalloc(&p, in_bytes, hipHostMallocDefault));
+        }
+        c->h_in_bytes = in_bytes;
+    }
+    if (out_bytes > c->h_out_bytes) {
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto &p : c->h_out) {
+            dfx_free_host(p);
+            HIPCHK(c, hipHostMalloc(&p, out_bytes, hipHostMallocDefault));
+        }
+        c->h_out_bytes = out_bytes;
+    }
+    return DFX_OK;
+}
+
 int ensure_staging(dfx_context *c, int u8_need, int flow_need) {
     if (u8_need > c->u8_slots) {
         HIPCHK(c, hipDeviceSynchronize());
@@ -165,6 +185,19 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             return rc;
     }
     const size_t plane = (size_t)c->W * c->H;
+    // Small frames: an asynchronous copy costs ~10 us of driver time whatever its size, and a 300-frame clip of
+    // 224x224 frames is ~900 of them (a third of the batch's compute time).  Such FlowBuffers go through page-locked
+    // bounce buffers instead: the host gathers / scatters the frames with memcpy and the copy stream moves one block
+    // per batch and direction.
+    const size_t in_fb = c->in_row_bytes() * c->in_h();
+    const size_t out_pb = out.quantized ? 2 * plane : plane * 8; // bytes per pair leaving the device
+    bool bounce = host_mode && in_fb <= (256u << 10) && (size_t)(B + astep) * in_fb <= (256u << 20) &&
+                  (size_t)B * out_pb <= (256u << 20);
+    if (bounce) {
+        rc = ensure_bounce(c, (size_t)(B + astep) * in_fb, (size_t)B * out_pb);
+        if (rc != DFX_OK)
+            return rc;
+    }
     const int F = E->frame_slots();
     c->h_slots.resize(F);
     c->h_pairs.resize(B);
@@ -189,15 +222,44 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         const BatchPlan &p = plan[k];
         const size_t rb = c->in_row_bytes(), fb = rb * c->in_h();
         unsigned char *dst = prep ? c->d_src[k & 1] : c->d_u8[k & 1];
-        for (int j = 0; j < p.n_new; ++j)
-            HIPCHK(c, copy_rows_async(dst + (size_t)j * fb, rb, frames[p.first_new + j], frame_pitch, rb, c->in_h(),
-                                      hipMemcpyHostToDevice, c->copy_stream));
+        if (bounce) {
+            if (k >= 2) // the copy that last read this bounce buffer (batch k-2) has long finished; make it formal
+                HIPCHK(c, hipEventSynchronize(c->ev_h2d[k & 1]));
+            unsigned char *hb = c->h_in[k & 1];
+            for (int j = 0; j < p.n_new; ++j) {
+                const uint8_t *src = frames[p.first_new + j];
+                if (frame_pitch == rb)
+                    std::memcpy(hb + (size_t)j * fb, src, fb);
+                else
+                    for (int y = 0; y < c->in_h(); ++y)
+                        std::memcpy(hb + (size_t)j * fb + (size_t)y * rb, src + (size_t)y * frame_pitch, rb);
+            }
+            if (p.n_new > 0)
+                HIPCHK(c, hipMemcpyAsync(dst, hb, (size_t)p.n_new * fb, hipMemcpyHostToDevice, c->copy_stream));
+        } else {
+            for (int j = 0; j < p.n_new; ++j)
+                HIPCHK(c, copy_rows_async(dst + (size_t)j * fb, rb, frames[p.first_new + j], frame_pitch, rb, c->in_h(),
+                                          hipMemcpyHostToDevice, c->copy_stream));
+        }
         HIPCHK(c, hipEventRecord(c->ev_h2d[k & 1], c->copy_stream));
         return DFX_OK;
     };
     auto download = [&](size_t k) -> int { // flows of batch k: staging set k&1 -> host (copy stream)
         const BatchPlan &p = plan[k];
         HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute[k & 1], 0));
+        if (bounce) { // one block per plane kind; scatter(k) hands the rows to the caller's buffers later
+            unsigned char *hb = c->h_out[k & 1];
+            if (out.quantized) {
+                HIPCHK(c, hipMemcpyAsync(hb, c->d_img[k & 1], (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, hipMemcpyAsync(hb + (size_t)p.nb * plane, c->d_img[k & 1] + (size_t)c->img_slots * plane,
+                                         (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->copy_stream));
+            } else {
+                HIPCHK(c, hipMemcpyAsync(hb, c->d_flow_out[k & 1], (size_t)p.nb * plane * 8, hipMemcpyDeviceToHost,
+                                         c->copy_stream));
+            }
+            HIPCHK(c, hipEventRecord(c->ev_d2h[k & 1], c->copy_stream));
+            return DFX_OK;
+        }
         for (int j = 0; j < p.nb; ++j) {
             if (out.quantized) {
                 const unsigned char *sx = c->d_img[k & 1] + (size_t)j * plane;
@@ -213,6 +275,28 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             }
         }
         HIPCHK(c, hipEventRecord(c->ev_d2h[k & 1], c->copy_stream));
+        return DFX_OK;
+    };
+
+    auto copy_rows = [](void *dst, size_t dpitch, const void *src, size_t row_bytes, int rows) {
+        if (dpitch == row_bytes)
+            std::memcpy(dst, src, row_bytes * rows);
+        else
+            for (int y = 0; y < rows; ++y)
+                std::memcpy((char *)dst + (size_t)y * dpitch, (const char *)src + (size_t)y * row_bytes, row_bytes);
+    };
+    auto scatter = [&](size_t k) -> int { // bounce mode: results of batch k -> the caller's buffers (host memcpy)
+        const BatchPlan &p = plan[k];
+        HIPCHK(c, hipEventSynchronize(c->ev_d2h[k & 1]));
+        const unsigned char *hb = c->h_out[k & 1];
+        for (int j = 0; j < p.nb; ++j) {
+            if (out.quantized) {
+                copy_rows(out.img_x[p.i0 + j], out.img_pitch, hb + (size_t)j * plane, c->W, c->H);
+                copy_rows(out.img_y[p.i0 + j], out.img_pitch, hb + ((size_t)p.nb + j) * plane, c->W, c->H);
+            } else {
+                copy_rows(out.flows[p.i0 + j], out.out_pitch, hb + (size_t)j * plane * 8, (size_t)c->W * 8, c->H);
+            }
+        }
         return DFX_OK;
     };
 
@@ -301,12 +385,22 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         rc = E->account(p.nb);
         if (rc != DFX_OK)
             return rc;
+        if (bounce && k >= 1) { // batch k-1 came down while batch k computed
+            rc = scatter(k - 1);
+            if (rc != DFX_OK)
+                return rc;
+        }
     }
     if (host_mode) {
         rc = download(plan.size() - 1);
         if (rc != DFX_OK)
             return rc;
         HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        if (bounce) {
+            rc = scatter(plan.size() - 1);
+            if (rc != DFX_OK)
+                return rc;
+        }
     }
     return DFX_OK;
 }
@@ -661,6 +755,10 @@ void dfx_destroy(dfx_handle h) {
         dfx_free_dev(p);
     for (auto &p : h->d_src)
         dfx_free_dev(p);
+    for (auto &p : h->h_in)
+        dfx_free_host(p);
+    for (auto &p : h->h_out)
+        dfx_free_host(p);
     for (auto &e : h->ev_h2d)
         if (e)
             (void)hipEventDestroy(e);

@@ -64,6 +64,9 @@ struct dfx_context {
     unsigned char *d_src[2] = {nullptr, nullptr}; // source-format frames before preparation (src_slots per set)
     int src_slots = 0;
     size_t src_frame_bytes = 0;
+    // page-locked bounce buffers for FlowBuffers of small frames: one copy per batch instead of one per frame
+    unsigned char *h_in[2] = {nullptr, nullptr}, *h_out[2] = {nullptr, nullptr};
+    size_t h_in_bytes = 0, h_out_bytes = 0;
     unsigned char *d_img[2] = {nullptr, nullptr}; // bounded output: img_slots x planes, then img_slots y planes
     int img_slots = 0;
     std::vector<int> h_slots;      // slot id of each new frame of the current batch
