@@ -53,31 +53,46 @@ __global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ f
                                                      int H, int pitch0, int dst_h, float ify,
                                                      const float *__restrict__ ker, int half,
                                                      float *__restrict__ tmpv, long long tmpv_frame_stride) {
+    // one thread = one column of one destination row: BOTH source rows the bilinear resize samples (y1, y1 + 1).
+    // Their tap windows overlap in all but one row each, so the interior path loads 2 values per tap pair for the
+    // two outputs (a rolling pair of registers supplies the other two) instead of 4.
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int q = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || q >= 2 * dst_h)
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || dy >= dst_h)
         return;
-    const int dy = q >> 1, r = q & 1;
     const float sy = (float)dy * ify;
     const int y1 = (int)floorf(sy);
-    const int yr = r ? min(y1 + 1, H - 1) : min(y1, H - 1);
+    const int yr0 = min(y1, H - 1), yr1 = min(y1 + 1, H - 1);
     const float *src = frames + (long long)blockIdx.z * frame_stride;
-    const float *centre = src + (long long)yr * pitch0 + x;
-    float v = centre[0] * ker[0];
-    if (yr - half >= 0 && yr + half <= H - 1) {
-        // window inside the frame (all but the first/last `half` rows): no border arithmetic per tap —
-        // BORDER_REFLECT_101 costs two integer modulos per tap pair, more than the tap itself
-#pragma unroll 8 // the taps are independent loads: let 16 of them be in flight per accumulation step
-        for (int j = 1; j <= half; ++j)
-            v = v + (centre[-(long long)j * pitch0] + centre[(long long)j * pitch0]) * ker[j];
-    } else {
+    float *out = tmpv + (long long)blockIdx.z * tmpv_frame_stride + (long long)(2 * dy) * pitch0 + x;
+    if (yr1 == yr0 + 1 && yr0 - half >= 0 && yr1 + half <= H - 1) {
+        const float *c0 = src + (long long)yr0 * pitch0 + x, *c1 = c0 + pitch0;
+        float lo_prev = c0[0], hi_prev = c1[0]; // row yr0 - (j-1) seen from output 1, row yr1 + (j-1) from output 0
+        float v0 = lo_prev * ker[0], v1 = hi_prev * ker[0];
+#pragma unroll 8
+        for (int j = 1; j <= half; ++j) {
+            const float lo = c0[-(long long)j * pitch0]; // row yr0 - j
+            const float hi = c1[(long long)j * pitch0];  // row yr1 + j
+            v0 = v0 + (lo + hi_prev) * ker[j];           // rows yr0 - j and yr0 + j = yr1 + (j-1)
+            v1 = v1 + (lo_prev + hi) * ker[j];           // rows yr1 - j = yr0 - (j-1) and yr1 + j
+            lo_prev = lo;
+            hi_prev = hi;
+        }
+        out[0] = v0;
+        out[pitch0] = v1;
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { // frame border: BORDER_REFLECT_101 per tap
+        const int yr = r ? yr1 : yr0;
+        float v = src[(long long)yr * pitch0 + x] * ker[0];
         for (int j = 1; j <= half; ++j) {
             const float a = src[(long long)reflect101_low(yr - j, H - 1) * pitch0 + x];
             const float b = src[(long long)reflect101_high(yr + j, H - 1) * pitch0 + x];
             v = v + (a + b) * ker[j];
         }
+        out[(long long)r * pitch0] = v;
     }
-    tmpv[(long long)blockIdx.z * tmpv_frame_stride + (long long)q * pitch0 + x] = v;
 }
 
 // pyr[z][dy][dx] = bilinear (E.1) of the blurred frame, the blur's horizontal pass (B.4) being
@@ -528,7 +543,7 @@ void farn_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long sr
 void farn_launch_blur_v(hipStream_t s, const float *frames, long long frame_stride, int n_frames, int W, int H,
                         int pitch0, int dst_h, float ify, const float *ker_half, int half, float *tmpv,
                         long long tmpv_frame_stride) {
-    hipLaunchKernelGGL(k_farn_blur_v, grid64x4(W, 2 * dst_h, n_frames), dim3(256), 0, s, frames, frame_stride, W, H,
+    hipLaunchKernelGGL(k_farn_blur_v, grid64x4(W, dst_h, n_frames), dim3(256), 0, s, frames, frame_stride, W, H,
                        pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride);
 }
 
