@@ -25,7 +25,7 @@ build/%.o: src/%.cpp $(wildcard include/*.h)
 build/libzzdenseflow.a: $(HOSTOBJ)
 	ar rcs $@ $^
 build/denseflow: tools/denseflow.cpp build/libzzdenseflow.a $(LIB)
-	$(CXX) $(CXXFLAGS) -o $@ tools/denseflow.cpp build/libzzdenseflow.a -Ldenseflow_amd/lib -ldfx -lpthread \
+	$(CXX) $(CXXFLAGS) -o $@ tools/denseflow.cpp build/libzzdenseflow.a -Ldenseflow_amd/lib -ldfx -lpthread -lz \
 	    -Wl,-rpath,'$$ORIGIN/../denseflow_amd/lib' -Wl,-rpath,/opt/rocm/lib
 
 oracle:

@@ -3,6 +3,8 @@
 // Host glue outside the hot path; nothing here runs on the GPU.
 #include "image_io.h"
 
+#include <zlib.h>
+
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -429,7 +431,7 @@ bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// PNG writer: 8-bit gray or BGR (stored as RGB), zlib "stored" blocks
+// PNG writer: 8-bit gray or BGR (stored as RGB), per-row None/Sub/Up filter, zlib level 1
 
 namespace {
 unsigned crc_table[256];
@@ -464,34 +466,41 @@ bool imencodePng(const Mat &img, vector<uchar> &out) {
     if (img.empty() || (img.type() != CV_8UC1 && img.type() != CV_8UC3))
         return false;
     const int ch = img.channels(), W = img.cols, H = img.rows;
-    vector<uchar> raw;
-    raw.reserve((size_t)H * (W * ch + 1));
+    const size_t rb = (size_t)W * ch;
+    // scanlines in PNG order (RGB), each with the cheapest of the filters None / Sub / Up by libpng's heuristic
+    // (smallest sum of absolute values of the filtered bytes taken as signed)
+    vector<uchar> raw((size_t)H * (rb + 1)), cur(rb), prev(rb, 0), cand(rb);
     for (int y = 0; y < H; ++y) {
-        raw.push_back(0); // filter: none
         const uchar *r = img.ptr<uchar>(y);
         if (ch == 1)
-            raw.insert(raw.end(), r, r + W);
+            std::memcpy(cur.data(), r, rb);
         else
-            for (int x = 0; x < W; ++x) {
-                raw.push_back(r[3 * x + 2]), raw.push_back(r[3 * x + 1]), raw.push_back(r[3 * x]);
+            for (int x = 0; x < W; ++x)
+                cur[3 * x] = r[3 * x + 2], cur[3 * x + 1] = r[3 * x + 1], cur[3 * x + 2] = r[3 * x];
+        uchar *dst = raw.data() + (size_t)y * (rb + 1);
+        unsigned long best = ~0ul;
+        for (int f = 0; f < 3; ++f) {
+            unsigned long cost = 0;
+            for (size_t i = 0; i < rb; ++i) {
+                const uchar pred = f == 0 ? 0 : f == 1 ? (i >= (size_t)ch ? cur[i - ch] : 0) : prev[i];
+                const uchar v = (uchar)(cur[i] - pred);
+                cand[i] = v;
+                cost += v < 128 ? v : 256 - v;
             }
-    }
-    vector<uchar> z;
-    z.push_back(0x78), z.push_back(0x01);
-    unsigned a = 1, b = 0;
-    for (size_t pos = 0; pos < raw.size();) {
-        const size_t n = std::min<size_t>(65535, raw.size() - pos);
-        z.push_back(pos + n == raw.size() ? 1 : 0);
-        z.push_back((uchar)(n & 0xFF)), z.push_back((uchar)(n >> 8));
-        z.push_back((uchar)(~n & 0xFF)), z.push_back((uchar)((~n >> 8) & 0xFF));
-        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
-        for (size_t i = pos; i < pos + n; ++i) {
-            a = (a + raw[i]) % 65521;
-            b = (b + a) % 65521;
+            if (cost < best) {
+                best = cost;
+                dst[0] = (uchar)f;
+                std::memcpy(dst + 1, cand.data(), rb);
+            }
         }
-        pos += n;
+        prev.swap(cur);
     }
-    put32(z, (b << 16) | a);
+    // zlib stream, level 1 (cv::imencode's default PNG compression level is 1 as well)
+    uLongf zlen = compressBound((uLong)raw.size());
+    vector<uchar> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 1) != Z_OK)
+        return false;
+    z.resize(zlen);
     out.clear();
     const uchar sig[] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     out.insert(out.end(), sig, sig + 8);

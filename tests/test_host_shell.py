@@ -65,7 +65,7 @@ def harness(built):
     so = os.path.join(out, "libhost_harness.so")
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-o", so,
            os.path.join(ROOT, "tests", "host_harness.cpp"), os.path.join(ROOT, "build", "libzzdenseflow.a"),
-           "-L" + os.path.join(ROOT, "denseflow_amd", "lib"), "-ldfx", "-lpthread",
+           "-L" + os.path.join(ROOT, "denseflow_amd", "lib"), "-ldfx", "-lpthread", "-lz",
            "-Wl,-rpath," + os.path.join(ROOT, "denseflow_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -166,6 +166,23 @@ def test_jpeg_transform_paths_agree_and_decode(harness, w, h):
     assert np.abs(dec["simd", 95] - gray).mean() < 2.0 and np.abs(dec["portable", 95] - gray).mean() < 2.0
     for quality in (95, 50):  # same coefficients up to rounding ties -> essentially the same picture
         assert np.abs(dec["simd", quality] - dec["portable", quality]).mean() < 0.1
+
+
+def test_png_is_compressed_and_lossless_on_a_smooth_flow(harness):
+    from PIL import Image
+
+    w, h = 320, 200
+    yy, xx = np.mgrid[0:h, 0:w]
+    fx = (2.5 * np.sin(xx / 40.0) * np.cos(yy / 35.0)).astype(np.float32)
+    fy = (1.5 * np.cos(xx / 50.0)).astype(np.float32)
+    buf = np.zeros(1 << 20, np.uint8)
+    n = harness.hh_encode_flow_png(fx.ctypes.data_as(C.c_void_p), fy.ctypes.data_as(C.c_void_p), w, h,
+                                   buf.ctypes.data_as(C.c_void_p), buf.size)
+    assert 0 < n < 0.35 * w * h * 3  # filtered + deflated, not stored
+    png = np.array(Image.open(io.BytesIO(buf[:n].tobytes())))
+    bx = int(png[0, 0, 0]) * 4
+    x_rec = (png[..., 2].astype(np.float64) - 128) * (bx / 128.0)
+    assert np.abs(x_rec - fx).max() <= bx / 128.0
 
 
 def test_png_and_jpeg_encoders_round_trip(harness):
