@@ -814,7 +814,8 @@ int dfx_memcpy_d2h(dfx_handle h, void *dst, const void *src, size_t bytes) {
 int dfx_host_alloc(void **ptr, size_t bytes) {
     if (!ptr)
         return DFX_ERR_INVALID;
-    return hipHostMalloc(ptr, bytes, hipHostMallocDefault) == hipSuccess ? DFX_OK : DFX_ERR_HIP;
+    // portable: the host shell's loader threads allocate frames that any device's handle may copy from
+    return hipHostMalloc(ptr, bytes, hipHostMallocPortable) == hipSuccess ? DFX_OK : DFX_ERR_HIP;
 }
 
 int dfx_host_free(void *ptr) { return hipHostFree(ptr) == hipSuccess ? DFX_OK : DFX_ERR_HIP; }

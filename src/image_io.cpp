@@ -26,7 +26,8 @@ bool VideoCapture::open(const string &file) {
         return false;
     }
     string cs = "420";
-    for (char *tok = strtok(line + 9, " \n"); tok; tok = strtok(nullptr, " \n")) {
+    char *save = nullptr; // strtok_r: several loader threads (one per device) open clips concurrently
+    for (char *tok = strtok_r(line + 9, " \n", &save); tok; tok = strtok_r(nullptr, " \n", &save)) {
         if (tok[0] == 'W')
             w_ = atoi(tok + 1);
         else if (tok[0] == 'H')

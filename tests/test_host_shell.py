@@ -349,6 +349,30 @@ def test_cli_device_resize_writes_the_same_files_as_host_resize(built, tmp_path,
 
 
 @pytest.mark.gpu
+def test_cli_two_pipelines_in_one_process_give_the_single_pipeline_files(built, tmp_path):
+    """The multi-GPU mode of the shell (one DenseFlow + one handle per device, videos dealt round-robin, no collective)
+    exercised on one GPU: DF_DEVICES=0,0 runs two complete pipelines concurrently on device 0."""
+    w, h, n, clips = 96, 72, 9, 5
+    lst = tmp_path / "list.txt"
+    names = []
+    for c in range(clips):
+        clip = tmp_path / f"v{c}.y4m"
+        write_y4m(clip, SynthClip(w, h, 30 + c).frames(n))
+        names.append(str(clip))
+    lst.write_text("\n".join(names) + "\n")
+    outs = {}
+    for tag, env in (("one", {}), ("two", {"DF_DEVICES": "0,0"})):
+        r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / tag), "-a=tvl1", "-s=1", "-b=20"],
+                           capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"{clips} videos ({clips * n} frames, {clips * (n - 1)} tvl1 flows) processed" in r.stdout, (tag, r.stdout)
+        outs[tag] = {str(p.relative_to(tmp_path / tag)): p.read_bytes()
+                     for p in sorted((tmp_path / tag).rglob("*")) if p.is_file()}
+    assert len(outs["one"]) == clips * (2 * (n - 1) + 1)  # flow_x / flow_y per pair + the .done marker per clip
+    assert outs["one"] == outs["two"]
+
+
+@pytest.mark.gpu
 def test_cli_end_to_end_on_gpu(built, oracle, tmp_path):
     """BASELINE config 1 shape: a 224x224 pair sequence, -a=tvl1 -s=1 -b=20, files named like the reference's."""
     from PIL import Image

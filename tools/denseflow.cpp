@@ -197,6 +197,20 @@ int main(int argc, char **argv) {
             const int avail = std::max(dfx_device_count(), 1);
             for (int g = 0; g < std::max(1, std::min(gpus, avail)); ++g)
                 devices.push_back(g);
+            if (const char *dl = std::getenv("DF_DEVICES")) { // explicit device list, e.g. "2,3" or (testing) "0,0"
+                devices.clear();
+                for (const char *q = dl; *q;) {
+                    char *end = nullptr;
+                    const long d = std::strtol(q, &end, 10);
+                    if (end == q)
+                        break;
+                    if (d >= 0 && d < avail)
+                        devices.push_back((int)d);
+                    q = (*end == ',') ? end + 1 : end;
+                }
+                if (devices.empty())
+                    devices.push_back(0);
+            }
             calcDenseFlowVideoMultiGPU(video_paths, output_dirs, algorithm, step, bound, new_width, new_height,
                                        new_short, has_class, use_frames, save_type, is_record, verbose, devices);
         }
