@@ -163,7 +163,7 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         return DFX_OK;
     HIPCHK(c, hipSetDevice(c->device));
     AlgoEngine *E = c->engine;
-    const int B = E->batch();
+    int B = E->batch();
     int rc = E->ensure_frame_slots(B + astep);
     if (rc != DFX_OK)
         return rc;
@@ -197,6 +197,11 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         rc = ensure_bounce(c, (size_t)(B + astep) * in_fb, (size_t)B * out_pb);
         if (rc != DFX_OK)
             return rc;
+    } else if (host_mode && M <= B && M >= 32) {
+        // Large frames, and the whole FlowBuffer would be one batch: nothing could overlap its copies.  Two balanced
+        // batches put the second upload and the first download under the compute (the engine's batch is sized for
+        // the device-resident path, where a bigger batch is simply better: 336 / 362 pairs/s at 32 / 128 for TVL1).
+        B = (M + 1) / 2;
     }
     const int F = E->frame_slots();
     c->h_slots.resize(F);

@@ -250,12 +250,12 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
         int frames_num;
         const bool do_resize = get_new_size(video_stream, frames_path, use_frames, size, frames_num);
         // Frames per FlowBuffer.  The reference fixes 512 (include/dense_flow.h:33); the three stages only
-        // overlap across buffers, so large frames get shorter buffers (>= 2 device batches each): 64 frames at
-        // 1080p, 512 from 512x512 down.  Buffer boundaries do not change any flow (the last |step| frames
+        // overlap across buffers, so large frames get shorter buffers (2 device batches each): 128 frames at
+        // 1080p, 512 from 724x724 down.  Buffer boundaries do not change any flow (the last |step| frames
         // are carried over, :204-207).
         const long long frame_px = std::max((long long)size.width * size.height,
                                             use_frames ? 0ll : (long long)video_stream.width() * video_stream.height());
-        batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, (128ll << 20) / std::max(1ll, frame_px)));
+        batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, (256ll << 20) / std::max(1ll, frame_px)));
         if (const char *bm = std::getenv("DF_BATCH_MAXSIZE")) // testing aid: force short buffers
             batch_maxsize = std::max(1, std::atoi(bm));
         if (verbose)
