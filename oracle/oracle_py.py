@@ -122,7 +122,7 @@ def _pick_threads(h: int, w: int, threads):
     short; on a 256-thread host the fork/join cost of every tiny parallel region dominates otherwise."""
     L = lib()
     if threads is None:
-        threads = max(1, min((h * w) // 16384, os.cpu_count() or 1))
+        threads = max(1, min((h * w) // 16384, os.cpu_count() or 1, 128))  # never more than one socket's worth
     L.orc_set_num_threads(int(threads))
     return L.orc_get_max_threads()
 
