@@ -1,5 +1,6 @@
 // tests/host_harness.cpp — TEST INFRASTRUCTURE: C wrappers around the host shell's codecs/quantisation and
 // the DenseFlow operator (calc_optflows_imp) so pytest can drive them through ctypes.
+#include <chrono>
 #include <cstring>
 
 #include "../include/dense_flow.h"
@@ -89,6 +90,53 @@ int hh_calc_optflows_imp_bounded(const uchar *frames, int n, int w, int h, const
         snprintf(err, err_cap, "%s", e.what());
         return -1;
     }
+}
+
+// FlowBufferQueue: a producer pushes n buffers (base_start = i, the last one final) through a queue of depth `depth`
+// while this thread pops until the final flag; returns the sum of the popped base_start values, or -1 on disorder.
+long hh_queue_roundtrip(int n, int depth) {
+    FlowBufferQueue q((size_t)depth);
+    thread producer([&] {
+        for (int i = 0; i < n; ++i)
+            q.push(FlowBuffer({}, path(), i, false), i == n - 1);
+    });
+    long sum = 0;
+    int expect = 0;
+    bool ok = true;
+    while (true) {
+        bool fin = false;
+        FlowBuffer b = q.pop(&fin);
+        ok = ok && b.base_start == expect++;
+        sum += b.base_start;
+        if (fin)
+            break;
+    }
+    producer.join();
+    return ok && expect == n ? sum : -1;
+}
+
+// close(): a consumer blocked on an empty queue wakes up with an empty final buffer, a producer blocked on a full
+// queue returns.  1 = both happened.
+int hh_queue_close_unblocks() {
+    FlowBufferQueue empty_q(2), full_q(1);
+    full_q.push(FlowBuffer({}, path(), 0, false), false);
+    std::atomic<int> woke(0);
+    thread consumer([&] {
+        bool fin = false;
+        FlowBuffer b = empty_q.pop(&fin);
+        if (fin && b.item_data.empty())
+            woke += 1;
+    });
+    thread producer([&] {
+        full_q.push(FlowBuffer({}, path(), 1, false), false); // blocks: depth 1 and nobody pops
+        woke += 1;
+    });
+    std::this_thread::sleep_for(std::chrono::milliseconds(50));
+    empty_q.close();
+    full_q.close();
+    consumer.join();
+    producer.join();
+    return woke.load() == 2;
 }
 
 // parallelFor: sum of i over [0, n) computed on `threads` workers; throws_at >= 0 makes that index throw.

@@ -237,6 +237,13 @@ def test_host_resize_is_the_oracles_cv_resize(harness, oracle, sw, sh, dw, dh):
     assert np.array_equal(dst, oracle.prepare_frame(src, dw, dh))
 
 
+def test_flow_buffer_queue_orders_blocks_and_closes(harness):
+    harness.hh_queue_roundtrip.restype = C.c_long
+    for n, depth in [(1, 1), (10, 1), (200, 3), (50, 64)]:
+        assert harness.hh_queue_roundtrip(n, depth) == n * (n - 1) // 2
+    assert harness.hh_queue_close_unblocks() == 1
+
+
 def test_parallel_for_covers_every_index_and_propagates_errors(harness):
     harness.hh_parallel_sum.restype = C.c_long
     for n, threads in [(0, 4), (1, 8), (100, 1), (1000, 7), (5, 64)]:
