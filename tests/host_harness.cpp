@@ -92,6 +92,36 @@ int hh_calc_optflows_imp_bounded(const uchar *frames, int n, int w, int h, const
     }
 }
 
+// N threads open the same .y4m clip `rounds` times each (the loader threads of a multi-device run do that
+// concurrently); returns the number of opens whose parsed geometry / frame count were wrong.
+int hh_parallel_open_y4m(const char *file, int threads, int rounds, int w, int h, int frames) {
+    std::atomic<int> bad(0);
+    parallelFor(threads, threads, [&](int) {
+        for (int r = 0; r < rounds; ++r) {
+            VideoCapture cap;
+            Mat first;
+            if (!cap.open(file) || cap.width() != w || cap.height() != h || cap.frameCount() != frames ||
+                !cap.read(first) || first.cols != w || first.rows != h)
+                bad += 1;
+        }
+    });
+    return bad.load();
+}
+
+// N threads encode the same gray image to JPEG; returns 1 when every stream is byte-identical to the serial one.
+int hh_parallel_jpeg(const uchar *gray, int w, int h, int threads) {
+    Mat m(Size(w, h), CV_8UC1);
+    memcpy(m.data(), gray, (size_t)w * h);
+    vector<uchar> ref;
+    imencodeJpeg(m, ref);
+    vector<vector<uchar>> outs(threads * 4);
+    parallelFor((int)outs.size(), threads, [&](int i) { imencodeJpeg(m, outs[i]); });
+    for (auto &o : outs)
+        if (o != ref)
+            return 0;
+    return 1;
+}
+
 // FlowBufferQueue: a producer pushes n buffers (base_start = i, the last one final) through a queue of depth `depth`
 // while this thread pops until the final flag; returns the sum of the popped base_start values, or -1 on disorder.
 long hh_queue_roundtrip(int n, int depth) {

@@ -237,6 +237,19 @@ def test_host_resize_is_the_oracles_cv_resize(harness, oracle, sw, sh, dw, dh):
     assert np.array_equal(dst, oracle.prepare_frame(src, dw, dh))
 
 
+def test_concurrent_clip_opens_and_encoders_are_thread_safe(harness, tmp_path):
+    """Regression: the Y4M header parser used strtok, so two loader threads (one per device in a multi-GPU run)
+    corrupted each other's parse and clips came out with one frame.  Also: parallel JPEG encoders share only
+    immutable tables."""
+    w, h, n = 48, 32, 5
+    frames = SynthClip(w, h, 3).frames(n)
+    clip = tmp_path / "c.y4m"
+    write_y4m(clip, frames)
+    assert harness.hh_parallel_open_y4m(str(clip).encode(), 8, 300, w, h, n) == 0
+    g = np.ascontiguousarray(frames[0])
+    assert harness.hh_parallel_jpeg(g.ctypes.data_as(C.c_void_p), w, h, 8) == 1
+
+
 def test_flow_buffer_queue_orders_blocks_and_closes(harness):
     harness.hh_queue_roundtrip.restype = C.c_long
     for n, depth in [(1, 1), (10, 1), (200, 3), (50, 64)]:
