@@ -435,22 +435,6 @@ bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
 // PNG writer: 8-bit gray or BGR (stored as RGB), per-row None/Sub/Up filter, zlib level 1
 
 namespace {
-unsigned crc_table[256];
-bool crc_ready = false;
-unsigned crc32_of(const uchar *p, size_t n, unsigned crc = 0xFFFFFFFFu) {
-    if (!crc_ready) {
-        for (unsigned i = 0; i < 256; ++i) {
-            unsigned c = i;
-            for (int k = 0; k < 8; ++k)
-                c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            crc_table[i] = c;
-        }
-        crc_ready = true;
-    }
-    for (size_t i = 0; i < n; ++i)
-        crc = crc_table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
-    return crc;
-}
 void put32(vector<uchar> &o, unsigned v) {
     o.push_back((uchar)(v >> 24)), o.push_back((uchar)(v >> 16)), o.push_back((uchar)(v >> 8)), o.push_back((uchar)v);
 }
@@ -459,7 +443,8 @@ void chunk(vector<uchar> &o, const char *type, const vector<uchar> &data) {
     const size_t start = o.size();
     o.insert(o.end(), type, type + 4);
     o.insert(o.end(), data.begin(), data.end());
-    put32(o, crc32_of(o.data() + start, o.size() - start) ^ 0xFFFFFFFFu);
+    // zlib's CRC-32 (the PNG chunk CRC); a lazily built local table here was a data race between parallel encoders
+    put32(o, (unsigned)crc32(0L, o.data() + start, (uInt)(o.size() - start)));
 }
 } // namespace
 
