@@ -339,6 +339,10 @@ def test_buffer_boundaries_do_not_change_the_output(built, tmp_path, source, ste
         outs[tag] = {p.name: p.read_bytes() for p in sorted(d.iterdir())}
     assert len(outs["one"]) == 2 * (n - step)
     assert outs["cut"] == outs["one"] and outs["cut3"] == outs["one"]
+    # file names as the reference writes them (src/common.cpp:84-100): "_p<step>_" for step > 1
+    first = "flow_x_00000.jpg" if step == 1 else f"flow_x_p{step}_00000.jpg"
+    last = f"flow_y_{n - step - 1:05d}.jpg" if step == 1 else f"flow_y_p{step}_{n - step - 1:05d}.jpg"
+    assert first in outs["one"] and last in outs["one"]
 
 
 @pytest.mark.gpu
