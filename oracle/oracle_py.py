@@ -113,6 +113,8 @@ def lib():
         L.orc_bgr2gray.argtypes = [_u8p, C.c_int, C.c_int, _u8p]
     if hasattr(L, "orc_flow_to_u8"):
         L.orc_flow_to_u8.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p]
+    if hasattr(L, "cpu_tvl1_calc"):
+        _bind_cpu_tvl1(L)
     _lib = L
     return L
 
@@ -279,3 +281,99 @@ def prepare_frame(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
     dst = np.empty((dh, dw), np.uint8)
     lib().orc_prepare_frame(src.reshape(-1), sw, sh, ch, dst, dw, dh)
     return dst
+
+
+# ---------------------------------------------------------------------------------------------- CPU DualTVL1 baseline
+class CpuTvl1Params(C.Structure):
+    _fields_ = [
+        ("tau", C.c_double),
+        ("lambda_", C.c_double),
+        ("theta", C.c_double),
+        ("nscales", C.c_int),
+        ("warps", C.c_int),
+        ("epsilon", C.c_double),
+        ("inner_iterations", C.c_int),
+        ("outer_iterations", C.c_int),
+        ("scale_step", C.c_double),
+        ("median_filtering", C.c_int),
+    ]
+
+
+class CpuTvl1Stats(C.Structure):
+    _fields_ = [
+        ("nscales", C.c_int),
+        ("w", C.c_int * 16),
+        ("h", C.c_int * 16),
+        ("inner_iterations", C.c_longlong),
+        ("outer_iterations", C.c_longlong),
+        ("px_iterations", C.c_double),
+    ]
+
+
+def _bind_cpu_tvl1(L):
+    L.cpu_tvl1_default_params.argtypes = [C.POINTER(CpuTvl1Params)]
+    L.cpu_tvl1_calc.argtypes = [_u8p, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.c_int, C.POINTER(CpuTvl1Params), _f32p,
+                                C.POINTER(CpuTvl1Stats)]
+    L.cpu_tvl1_calc.restype = C.c_int
+    L.cpu_tvl1_resize_linear.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_double, C.c_double]
+    L.cpu_tvl1_median_blur.argtypes = [_f32p, _f32p, C.c_int, C.c_int, C.c_int]
+    L.cpu_tvl1_remap_cubic.argtypes = [_f32p, C.c_int, C.c_int, _f32p, _f32p, _f32p]
+    L.cpu_tvl1_cubic_coeffs.argtypes = [C.c_float, C.POINTER(C.c_float * 4)]
+
+
+_native_cpu_tvl1 = None
+
+
+def cpu_tvl1_native_lib():
+    """oracle/cpu_tvl1_baseline.c compiled ON THIS MACHINE with -O3 -march=native (the CPU
+    comparator is built for the host it is timed on).  Falls back to the portable copy inside liboracle.so when
+    no compiler is available."""
+    global _native_cpu_tvl1
+    if _native_cpu_tvl1 is not None:
+        return _native_cpu_tvl1
+    import hashlib
+    import platform
+
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln for ln in f if ln.startswith("model name")), platform.processor())
+    except OSError:
+        model = platform.processor()
+    tag = hashlib.sha1(model.encode()).hexdigest()[:10]
+    out = os.path.join(_HERE, "_native", f"libcpu_tvl1_{tag}.so")
+    src = os.path.join(_HERE, "cpu_tvl1_baseline.c")
+    L = None
+    try:
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-shared", "-fopenmp",
+                            "-ffp-contract=off", "-D_GNU_SOURCE", "-o", out, src, "-lm"], check=True,
+                           capture_output=True)
+        L = C.CDLL(out)
+        _bind_cpu_tvl1(L)
+    except Exception:
+        L = lib()
+    _native_cpu_tvl1 = L
+    return L
+
+
+def cpu_tvl1_default_params() -> CpuTvl1Params:
+    p = CpuTvl1Params()
+    lib().cpu_tvl1_default_params(C.byref(p))
+    return p
+
+
+def cpu_tvl1_calc(frame0: np.ndarray, frame1: np.ndarray, params: CpuTvl1Params | None = None, want_stats=False,
+                  native: bool = False):
+    """CPU cv::optflow::DualTVL1OpticalFlow restatement (oracle/cpu_tvl1_baseline.c) — the timing comparator."""
+    f0 = np.ascontiguousarray(frame0, dtype=np.uint8)
+    f1 = np.ascontiguousarray(frame1, dtype=np.uint8)
+    assert f0.shape == f1.shape and f0.ndim == 2
+    h, w = f0.shape
+    flow = np.empty((h, w, 2), dtype=np.float32)
+    st = CpuTvl1Stats()
+    L = cpu_tvl1_native_lib() if native else lib()
+    rc = L.cpu_tvl1_calc(f0, w, f1, w, w, h, C.byref(params) if params is not None else None, flow, C.byref(st))
+    if rc != 0:
+        raise ValueError("cpu_tvl1_calc rejected the parameters")
+    return (flow, st) if want_stats else flow

@@ -26,7 +26,10 @@ for cfg in configs:
     parts = [int(v) for v in cfg.split(":")]
     impl, k, b = parts[:3]
     th = parts[3] if len(parts) > 3 else 0
-    eng = denseflow_amd.FlowEngine(W, H, ALGO, impl=impl, tvl1_fuse_k=k, max_batch=b, tvl1_tile_h=th)
+    extra = {"tvl1_nscales": int(os.environ["NSCALES"])} if os.environ.get("NSCALES") else {}
+    if os.environ.get("EPS"):
+        extra["tvl1_epsilon"] = float(os.environ["EPS"])
+    eng = denseflow_amd.FlowEngine(W, H, ALGO, impl=impl, tvl1_fuse_k=k, max_batch=b, tvl1_tile_h=th, **extra)
     run = lambda: eng.calc_optflows_device(d_frames.data_ptr(), W, W * H, NF, 1, d_flows.data_ptr(), W * H * 2)
     run()
     eng.reset_stats()
