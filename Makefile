@@ -8,7 +8,7 @@ CXXFLAGS ?= -O3 -std=c++17 -Wall -Wextra -fPIC -Iinclude
 CSRC     := $(wildcard denseflow_amd/csrc/*.hip denseflow_amd/csrc/*.cpp)
 CHDR     := $(wildcard denseflow_amd/csrc/*.h) include/dfx.h
 LIB      := denseflow_amd/lib/libdfx.so
-HOSTSRC  := src/common.cpp src/utils.cpp src/image_io.cpp src/denseflow_gpu.cpp
+HOSTSRC  := src/common.cpp src/utils.cpp src/image_io.cpp src/h5mini.cpp src/denseflow_gpu.cpp
 HOSTOBJ  := $(patsubst src/%.cpp,build/%.o,$(HOSTSRC))
 
 all: lib host oracle

@@ -242,6 +242,7 @@ static void stage2(const brox_level *L) {
 
 static void sor_pass(const brox_level *L, const float *u, const float *v, int color, float omega) {
     const int w = L->w, h = L->h;
+    const int jacobi = (orc_get_variant() & ORC_VAR_BROX_JACOBI) != 0;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; ++y)
         for (int x = (y + color) & 1; x < w; x += 2) {
@@ -261,7 +262,8 @@ static void sor_pass(const brox_level *L, const float *u, const float *v, int co
                              gs * v[o];
             const float du = L->du[o], dv = L->dv[o];
             const float du_n = (1.0f - omega) * du + omega * (L->inv_den_u[o] * ((su - L->num_u[o]) - L->num_dudv[o] * dv));
-            const float dv_n = (1.0f - omega) * dv + omega * (L->inv_den_v[o] * ((sv - L->num_v[o]) - L->num_dudv[o] * du_n));
+            const float du_c = jacobi ? du : du_n; /* upstream overwrites du before it forms dv (Gauss-Seidel) */
+            const float dv_n = (1.0f - omega) * dv + omega * (L->inv_den_v[o] * ((sv - L->num_v[o]) - L->num_dudv[o] * du_c));
             L->du[o] = du_n;
             L->dv[o] = dv_n;
         }
@@ -317,7 +319,7 @@ int orc_brox_calc(const uint8_t *I0u8, size_t pitch0, const uint8_t *I1u8, size_
         memset(u, 0, sizeof(float) * nc);
         memset(v, 0, sizeof(float) * nc);
     }
-    const float omega = 1.99f;
+    const float omega = orc_get_brox_omega(); /* 1.99f unless a test changes it */
     for (int l = nl - 1; l >= 0; --l) {
         const int w = wh[2 * l], h = wh[2 * l + 1];
         const size_t n = (size_t)w * h;

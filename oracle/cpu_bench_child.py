@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""bench.py's `cpu_baseline` leg, run as a child process — TEST / BENCH INFRASTRUCTURE ONLY.
+
+    python oracle/cpu_bench_child.py <frames.npy> <kind> <budget_s>
+        kind = cpu_tvl1 : oracle/cpu_tvl1_baseline.c, the restatement of CPU cv::optflow::DualTVL1OpticalFlow
+                          (the comparator BASELINE.json's north_star names), built here with -O3 -march=native
+               tvl1 | farn | brox : the parity oracle (cv::cuda semantics), timed as a second CPU point
+
+A child process so that the OpenMP runtime starts with a placement chosen HERE, before any library is loaded:
+one thread per physical core of the CPUs this process may run on, pinned (GOMP_CPU_AFFINITY).  Round 1 timed the
+oracle inside the bench process after the HIP runtime was up and got 0.21 and 0.65 pairs/s on two boxes of the same
+class; unpinned 256-thread teams across both sockets were up to 100x slower still.  The sample is run three
+times and the median is reported, with the spread, so that an unstable box is visible in the JSON line.
+Prints one JSON object."""
+import json
+import os
+import sys
+import time
+
+
+def physical_cores(allowed):
+    """One logical CPU per physical core among `allowed`, sorted by (package, core)."""
+    seen, pick = set(), []
+    for cpu in sorted(allowed):
+        base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+        try:
+            with open(base + "physical_package_id") as f:
+                pkg = int(f.read())
+            with open(base + "core_id") as f:
+                core = int(f.read())
+        except (OSError, ValueError):
+            pkg, core = 0, cpu
+        if (pkg, core) not in seen:
+            seen.add((pkg, core))
+            pick.append((pkg, core, cpu))
+    pick.sort()
+    return [c for _, _, c in pick]
+
+
+def main():
+    path, kind, budget = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    allowed = os.sched_getaffinity(0)
+    cpus = physical_cores(allowed)
+    cap = int(os.environ.get("DFX_CPU_THREADS", "0"))
+    if cap > 0:
+        cpus = cpus[:cap]
+    os.environ["OMP_NUM_THREADS"] = str(len(cpus))
+    os.environ["GOMP_CPU_AFFINITY"] = " ".join(str(c) for c in cpus)
+    os.environ["OMP_PROC_BIND"] = "true"
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import numpy as np
+
+    from oracle import oracle_py as O
+
+    frames = np.load(path)
+    O.build()
+    if kind == "cpu_tvl1":
+        fn = lambda a, b: O.cpu_tvl1_calc(a, b, native=True)
+        what = "oracle/cpu_tvl1_baseline.c (CPU cv::optflow::DualTVL1OpticalFlow restatement, create() defaults: " \
+               "10 outer x 30 inner iterations, 5x5 median, cubic remap), gcc -O3 -march=native, OpenMP"
+    else:
+        base = {"tvl1": O.tvl1_calc, "farn": O.farneback_calc, "brox": O.brox_calc}[kind]
+        fn = lambda a, b: base(a, b, threads=len(cpus))
+        what = f"oracle/ ({kind}, cv::cuda semantics, the parity oracle), gcc -O2, OpenMP"
+    t0 = time.perf_counter()
+    fn(frames[0], frames[1])  # warm-up: thread team, page faults, table construction
+    t1 = time.perf_counter() - t0
+    n = int(max(1, min(len(frames) - 1, (budget / 3.0) // max(t1, 1e-3))))
+    runs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(frames[i], frames[i + 1])
+        runs.append(n / (time.perf_counter() - t0))
+    runs.sort()
+    h, w = frames[0].shape
+    print(json.dumps({
+        "value": runs[1],
+        "unit": "frame-pairs/s",
+        "cores": len(cpus),
+        "runs": runs,
+        "spread": (runs[2] - runs[0]) / runs[1],
+        "sample": f"median of 3 runs over {n} consecutive pairs of the same {w}x{h} clip; {what}; "
+                  f"{len(cpus)} threads pinned one per physical core ({len(allowed)} logical CPUs allowed)",
+    }))
+
+
+if __name__ == "__main__":
+    main()

@@ -117,7 +117,7 @@ void orc_farneback_prepare_poly(int n, double sigma, orc_farneback_poly_consts *
 int orc_farneback_gaussian_kernel(int n, double sigma, float *k) {
     if (n < 1 || !(n & 1))
         return -1;
-    if (sigma <= 0) {
+    if (sigma <= 0 && !(orc_get_variant() & ORC_VAR_FARN_SIGMA0_COMPUTED)) {
         static const double t1[] = {1.};
         static const double t3[] = {0.25, 0.5, 0.25};
         static const double t5[] = {0.0625, 0.25, 0.375, 0.25, 0.0625};

@@ -82,6 +82,16 @@ def lib():
     if not os.path.exists(_LIB_PATH):
         build()
     L = C.CDLL(_LIB_PATH)
+    _bind_all(L)
+    _lib = L
+    return L
+
+
+def _bind_all(L):
+    L.orc_set_variant.argtypes = [C.c_int]
+    L.orc_get_variant.restype = C.c_int
+    L.orc_set_brox_omega.argtypes = [C.c_float]
+    L.orc_get_brox_omega.restype = C.c_float
     L.orc_set_num_threads.argtypes = [C.c_int]
     L.orc_get_max_threads.restype = C.c_int
     L.orc_tvl1_default_params.argtypes = [C.POINTER(Tvl1Params)]
@@ -115,8 +125,31 @@ def lib():
         L.orc_flow_to_u8.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_double, _u8p, _u8p]
     if hasattr(L, "cpu_tvl1_calc"):
         _bind_cpu_tvl1(L)
-    _lib = L
     return L
+
+
+# reading variants (oracle_common.h): flags for `variant(...)`
+VAR_TVL1_BREAK_BEFORE_DUAL, VAR_TVL1_SUM_FLOAT, VAR_TVL1_SQRT_HYPOT = 1, 2, 4
+VAR_FARN_SIGMA0_COMPUTED, VAR_BROX_JACOBI, VAR_BROX_CONVERT_DOUBLE = 8, 16, 32
+
+
+class variant:
+    """with oracle_py.variant(flags, brox_omega=...): the oracle evaluates an alternative reading of upstream."""
+
+    def __init__(self, flags: int = 0, brox_omega: float = 0.0):
+        self.flags, self.omega = int(flags), float(brox_omega)
+
+    def __enter__(self):
+        L = lib()
+        self._old = (L.orc_get_variant(), L.orc_get_brox_omega())
+        L.orc_set_variant(self.flags)
+        L.orc_set_brox_omega(self.omega)
+        return self
+
+    def __exit__(self, *a):
+        L = lib()
+        L.orc_set_variant(self._old[0])
+        L.orc_set_brox_omega(self._old[1])
 
 
 def _pick_threads(h: int, w: int, threads):

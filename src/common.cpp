@@ -2,6 +2,7 @@
 // Behaviour follows /root/reference/src/common.cpp: CAST quantisation :4-16, PNG scheme :18-46,
 // encodeFlowMap :48-64, file naming :73-118.  Host glue, not on the GPU path.
 #include "common.h"
+#include "h5mini.h"
 
 #include <algorithm>
 #include <cmath>
@@ -219,3 +220,29 @@ void writeFlowImagesPng(vector<vector<uchar>> images, string name_prefix, const 
     for (size_t i = 0; i < images.size(); ++i)
         write_blob(name_prefix + flow_suffix(step, start + (int)i, ".png"), images[i]);
 }
+
+// -st=h5 (reference: writeHDF5, /root/reference/src/common.cpp:121-149, built there only with USE_HDF5=ON): the file
+// `<name_prefix>.h5` (`_p%d.h5` / `_m%d.h5` for other steps) was created when the video was opened; every
+// FlowBuffer adds one float dataset per flow, `/<phase>_%05d` with the step infix of the image files.
+string h5FileName(const string &name_prefix, int step) {
+    char ext[32];
+    if (step > 1)
+        snprintf(ext, sizeof ext, "_p%d.h5", step);
+    else if (step < 0)
+        snprintf(ext, sizeof ext, "_m%d.h5", -step);
+    else
+        snprintf(ext, sizeof ext, ".h5");
+    return name_prefix + ext;
+}
+
+void createHDF5(const string &name_prefix, int step) { h5mini::create(h5FileName(name_prefix, step)); }
+
+void writeHDF5(const vector<Mat> &images, string name_prefix, string phase, const int step, const int start) {
+    vector<h5mini::FloatDataset> ds;
+    ds.reserve(images.size());
+    for (size_t i = 0; i < images.size(); ++i)
+        ds.push_back({phase + flow_suffix(step, start + (int)i, ""), (size_t)images[i].rows, (size_t)images[i].cols,
+                      images[i].ptr<float>(), images[i].step});
+    h5mini::append(h5FileName(name_prefix, step), ds);
+}
+

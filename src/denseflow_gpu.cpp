@@ -232,8 +232,8 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
     for (size_t i = 0; i < video_paths.size(); i++) {
         const path video_path = video_paths[i];
         const path output_dir = output_dirs[i];
-        if (save_type == "h5") // this build has no HDF5, like the reference compiled with USE_HDF5=OFF (:238)
-            throw std::runtime_error("HDF5 support is not enabled, pls recompile");
+        if (save_type == "h5") // create <output_dir>.h5 (reference :223-243); encode_save appends per FlowBuffer
+            createHDF5(output_dir.string(), step);
         VideoCapture video_stream;
         vector<path> frames_path;
         if (use_frames) {
@@ -388,6 +388,16 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
                 encodeFlowMapPng(planes[0], planes[1], output[i]);
             });
             writeFlowImagesPng(output, (flow_buffer.output_dir / "flow").string(), step, flow_buffer.base_start);
+        } else if (save_type == "h5") { // unbounded float planes (reference :429-441)
+            vector<Mat> output_h5_x(M), output_h5_y(M);
+            parallelFor(M, encode_threads, [&](int i) {
+                Mat planes[2];
+                split(flow_buffer.item_data[i], planes);
+                output_h5_x[i] = planes[0];
+                output_h5_y[i] = planes[1];
+            });
+            writeHDF5(output_h5_x, flow_buffer.output_dir.string(), "flow_x", step, flow_buffer.base_start);
+            writeHDF5(output_h5_y, flow_buffer.output_dir.string(), "flow_y", step, flow_buffer.base_start);
         }
         // mark the video done after its last buffer has been written (resume support, :456-470)
         if (is_record && flow_buffer.last_buffer) {

@@ -92,3 +92,24 @@ def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
         with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver) as eng:
             fused = eng.calc(f0, f1)
         assert np.array_equal(simple, fused), solver
+
+
+def test_config5_shape_4k_step2(dfx, oracle):
+    """BASELINE config 5 at its stated frame size: 3840x2160, -a=brox -s=2 (reference call
+    src/denseflow_gpu.cpp:303, :331-334 with the pair rule of :315-316).  Four frames through the FlowBuffer entry
+    point give two flows (0 -> 2, 1 -> 3); both are compared with the oracle, and the 24-level pyramid is checked."""
+    w, h, n = 3840, 2160, 4
+    clip = SynthClip(w, h, 5)  # SURVEY.md §8d: config 5 is seed 5
+    frames = clip.frames(n)
+    with dfx.FlowEngine(w, h, "brox") as eng:
+        flows = eng.calc_optflows(frames, 2)
+        st = eng.stats()
+    assert len(flows) == n - 2
+    sizes = oracle.brox_pyramid_sizes(w, h)
+    assert len(sizes) == 24 and st.levels == min(len(sizes), 16)
+    for i in range(n - 2):
+        ref = oracle.brox_calc(frames[i], frames[i + 2])
+        assert np.max(np.abs(flows[i] - ref)) <= TOL, i
+        assert np.array_equal(flows[i], ref), i
+    gt = clip.true_flow(0, 2)
+    assert np.abs(flows[0] - gt)[128:-128, 128:-128].mean() < 0.05

@@ -423,3 +423,65 @@ def test_cli_end_to_end_on_gpu(built, oracle, tmp_path):
     r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / "out"), "-a=tvl1", "-s=1", "-b=20", "-v"],
                        capture_output=True, text=True)
     assert r.returncode == 0 and "skip" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("step,algo", [(1, "tvl1"), (-2, "farn")])
+def test_cli_h5_output_holds_the_unbounded_float_flows(built, oracle, tmp_path, step, algo):
+    """-st=h5 (reference src/denseflow_gpu.cpp:223-243, :429-441, src/common.cpp:121-149): `<out>/<stem>.h5` (with the
+    `_m2` infix for -s=-2) holds /flow_x_%05d and /flow_y_%05d, rank-2 float datasets = the two channels of each
+    CV_32FC2 flow, unbounded.  Read back with the independent parser and compared with the oracle bit for bit."""
+    from tests import h5_min_reader
+
+    w, h, n = 96, 64, 7
+    frames = SynthClip(w, h, 6).frames(n)
+    calc = oracle.tvl1_calc if algo == "tvl1" else oracle.farneback_calc
+    a = abs(step)
+    clip = tmp_path / "clip.y4m"
+    write_y4m(clip, frames)
+    env = dict(os.environ, DF_BATCH_MAXSIZE="4")  # several FlowBuffers: the file is re-opened and appended to
+    r = subprocess.run([built, str(clip), "-o=" + str(tmp_path / "out"), f"-a={algo}", f"-s={step}", "-st=h5"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    name = "clip.h5" if step == 1 else ("clip_p%d.h5" % step if step > 1 else "clip_m%d.h5" % a)
+    got = h5_min_reader.read(str(tmp_path / "out" / name))
+    base = 0 if step > 0 else a
+    infix = "" if step == 1 else ("_p%d" % step if step > 1 else "_m%d" % a)
+    assert len(got) == 2 * (n - a)
+    for i in range(n - a):
+        fa, fb = (i, i + step) if step > 0 else (i - step, i)
+        ref = calc(frames[fa], frames[fb])
+        assert np.array_equal(got["flow_x%s_%05d" % (infix, i + base)], ref[..., 0]), i
+        assert np.array_equal(got["flow_y%s_%05d" % (infix, i + base)], ref[..., 1]), i
+
+
+@pytest.mark.gpu
+def test_cli_videolist_sharded_over_device_pipelines_matches_the_oracle(built, oracle, tmp_path):
+    """BASELINE config 4 shape (a list of 224x224 clips, -a=tvl1, sharded over the GPUs of a node) at test size:
+    8 clips through `-g` with two pipelines (on a 1-GPU box both on device 0, DF_DEVICES=0,0).  Every flow file of
+    every clip must be the JPEG of the ORACLE's bounded flow, exactly the bytes the shell's encoder makes of it."""
+    from PIL import Image
+
+    w, h, n, clips = 224, 224, 4, 8
+    lst = tmp_path / "list.txt"
+    refs = {}
+    with open(lst, "w") as f:
+        for c in range(clips):
+            frames = SynthClip(w, h, 1000 + c).frames(n)  # SURVEY.md §8d: seed 1000 + clip
+            p = tmp_path / f"v{c:02d}.y4m"
+            write_y4m(p, frames)
+            f.write(str(p) + "\n")
+            refs[c] = [oracle.flow_to_u8(oracle.tvl1_calc(frames[i], frames[i + 1]), -20, 20) for i in range(n - 1)]
+    env = dict(os.environ, DF_DEVICES="0,0")
+    r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / "out"), "-a=tvl1", "-s=1", "-b=20", "-g=2"],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"{clips} videos" in r.stdout
+    for c in range(clips):
+        assert (tmp_path / "out" / ".done" / f"v{c:02d}").is_file()
+        for i in range(n - 1):
+            for k, name in enumerate(("flow_x", "flow_y")):
+                img = np.array(Image.open(tmp_path / "out" / f"v{c:02d}" / f"{name}_{i:05d}.jpg")).astype(np.int32)
+                q = refs[c][i][k].astype(np.int32)
+                assert img.shape == q.shape
+                assert np.abs(img - q).max() <= 6 and np.abs(img - q).mean() < 0.6, (c, i, name)  # JPEG q95 of the oracle's plane
