@@ -49,9 +49,34 @@ void default_params(dfx_params *p) {
     p->brox_solver_iterations = 10;
 }
 
+} // namespace
+
+int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity) {
+    int rc = DFX_OK;
+    for (auto it = c->tails.begin(); it != c->tails.end();) {
+        dfx_context::Tail &t = **it;
+        if ((up_to == 0 || t.ticket <= up_to) && (parity < 0 || t.parity == parity)) {
+            if (t.worker.joinable())
+                t.worker.join();
+            if (t.rc != DFX_OK && rc == DFX_OK) {
+                rc = t.rc;
+                c->err = t.err;
+            }
+            it = c->tails.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return rc;
+}
+
+namespace {
+
 int ensure_img_staging(dfx_context *c, int img_need) {
     if (img_need > c->img_slots) {
+        (void)dfx_finish_tails(c, 0, -1);
         HIPCHK(c, hipDeviceSynchronize());
+        c->img_slots = 0; // a failed allocation below must not leave the old size standing
         for (auto &p : c->d_img) {
             dfx_free_dev(p);
             HIPCHK(c, hipMalloc(&p, (size_t)img_need * 2 * c->W * c->H)); // img_need x planes, then the y planes
@@ -64,7 +89,10 @@ int ensure_img_staging(dfx_context *c, int img_need) {
 int ensure_src_staging(dfx_context *c, int need) {
     const size_t fb = c->in_row_bytes() * c->in_h();
     if (need > c->src_slots || fb != c->src_frame_bytes) {
+        (void)dfx_finish_tails(c, 0, -1);
         HIPCHK(c, hipDeviceSynchronize());
+        c->src_slots = 0;
+        c->src_frame_bytes = 0;
         for (auto &p : c->d_src) {
             dfx_free_dev(p);
             HIPCHK(c, hipMalloc(&p, (size_t)need * fb));
@@ -77,7 +105,9 @@ int ensure_src_staging(dfx_context *c, int need) {
 
 int ensure_bounce(dfx_context *c, size_t in_bytes, size_t out_bytes) {
     if (in_bytes > c->h_in_bytes) {
+        (void)dfx_finish_tails(c, 0, -1);
         HIPCHK(c, hipDeviceSynchronize());
+        c->h_in_bytes = 0;
         for (auto &p : c->h_in) {
             dfx_free_host(p);
             HIPCHK(c, hipHostMalloc(&p, in_bytes, hipHostMallocDefault));
@@ -85,7 +115,9 @@ int ensure_bounce(dfx_context *c, size_t in_bytes, size_t out_bytes) {
         c->h_in_bytes = in_bytes;
     }
     if (out_bytes > c->h_out_bytes) {
+        (void)dfx_finish_tails(c, 0, -1);
         HIPCHK(c, hipDeviceSynchronize());
+        c->h_out_bytes = 0;
         for (auto &p : c->h_out) {
             dfx_free_host(p);
             HIPCHK(c, hipHostMalloc(&p, out_bytes, hipHostMallocDefault));
@@ -97,7 +129,9 @@ int ensure_bounce(dfx_context *c, size_t in_bytes, size_t out_bytes) {
 
 int ensure_staging(dfx_context *c, int u8_need, int flow_need) {
     if (u8_need > c->u8_slots) {
+        (void)dfx_finish_tails(c, 0, -1);
         HIPCHK(c, hipDeviceSynchronize());
+        c->u8_slots = 0;
         for (auto &p : c->d_u8) {
             dfx_free_dev(p);
             HIPCHK(c, hipMalloc(&p, (size_t)u8_need * c->W * c->H));
@@ -105,7 +139,9 @@ int ensure_staging(dfx_context *c, int u8_need, int flow_need) {
         c->u8_slots = u8_need;
     }
     if (flow_need > c->flow_slots) {
+        (void)dfx_finish_tails(c, 0, -1);
         HIPCHK(c, hipDeviceSynchronize());
+        c->flow_slots = 0;
         for (auto &p : c->d_flow_out) {
             dfx_free_dev(p);
             HIPCHK(c, hipMalloc(&p, (size_t)flow_need * c->W * c->H * 2 * sizeof(float)));
@@ -153,8 +189,16 @@ struct BatchPlan {
 //                and the flows of batch i-1 come down while batch i computes (the reference uploads,
 //                computes and downloads one pair at a time with a blocking download, :317-339).
 //   device mode: d_frames / d_flows contiguous device arrays, no copies at all.
-int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_pitch, const uint8_t *d_frames,
-                    size_t d_pitch, size_t d_frame_stride, int n_frames, int step, const OutSpec &out) {
+//   ticket != nullptr (dfx_submit_*): the call returns when the device work of the FlowBuffer is done and every
+//                batch but the last has been handed over; the last download (+ hand-over) finishes on a helper
+//                thread (dfx_context::Tail) and is awaited by dfx_wait(ticket).
+int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_pitch, const uint8_t *d_frames,
+                    size_t d_pitch, size_t d_frame_stride, int n_frames, int step, const OutSpec &out,
+                    unsigned long long *ticket) {
+    if (ticket)
+        *ticket = 0;
+    else
+        (void)dfx_finish_tails(c, 0, -1); // synchronous entry points never run beside a deferred tail
     if (n_frames < 0 || step == 0)
         return dfx_fail(c, DFX_ERR_INVALID, "n_frames must be >= 0 and step non-zero");
     const int astep = std::abs(step);
@@ -223,14 +267,21 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             plan.push_back(p);
         }
     }
-    auto upload = [&](size_t k) -> int { // host frames of batch k -> staging set k&1 (copy stream)
+    // batches are numbered across calls (q = seq0 + k): batch q uses staging set / bounce buffer / events q & 1
+    const unsigned long long seq0 = c->batch_seq;
+    c->batch_seq += plan.size();
+    auto par = [&](size_t k) -> int { return (int)((seq0 + k) & 1ull); };
+    auto upload = [&](size_t k) -> int { // host frames of batch k -> staging set par(k) (upload stream)
         const BatchPlan &p = plan[k];
         const size_t rb = c->in_row_bytes(), fb = rb * c->in_h();
-        unsigned char *dst = prep ? c->d_src[k & 1] : c->d_u8[k & 1];
+        unsigned char *dst = prep ? c->d_src[par(k)] : c->d_u8[par(k)];
+        // the staging set was last read by the frame preparation of batch q-2 (compute stream)
+        if (seq0 + k >= 2)
+            HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute[par(k)], 0));
         if (bounce) {
-            if (k >= 2) // the copy that last read this bounce buffer (batch k-2) has long finished; make it formal
-                HIPCHK(c, hipEventSynchronize(c->ev_h2d[k & 1]));
-            unsigned char *hb = c->h_in[k & 1];
+            if (seq0 + k >= 2) // the copy that last read this bounce buffer (batch q-2) has long finished; make it formal
+                HIPCHK(c, hipEventSynchronize(c->ev_h2d[par(k)]));
+            unsigned char *hb = c->h_in[par(k)];
             for (int j = 0; j < p.n_new; ++j) {
                 const uint8_t *src = frames[p.first_new + j];
                 if (frame_pitch == rb)
@@ -246,40 +297,45 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 HIPCHK(c, copy_rows_async(dst + (size_t)j * fb, rb, frames[p.first_new + j], frame_pitch, rb, c->in_h(),
                                           hipMemcpyHostToDevice, c->copy_stream));
         }
-        HIPCHK(c, hipEventRecord(c->ev_h2d[k & 1], c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev_h2d[par(k)], c->copy_stream));
         return DFX_OK;
     };
-    auto download = [&](size_t k) -> int { // flows of batch k: staging set k&1 -> host (copy stream)
+    auto download = [&](size_t k) -> int { // flows of batch k: staging set par(k) -> host (download stream)
         const BatchPlan &p = plan[k];
-        HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute[k & 1], 0));
+        const int q = par(k);
+        HIPCHK(c, hipStreamWaitEvent(c->d2h_stream, c->ev_compute[q], 0));
         if (bounce) { // one block per plane kind; scatter(k) hands the rows to the caller's buffers later
-            unsigned char *hb = c->h_out[k & 1];
+            // a deferred tail of an earlier FlowBuffer may still have to empty this bounce buffer
+            const int trc = dfx_finish_tails(c, 0, q);
+            if (trc != DFX_OK)
+                return trc;
+            unsigned char *hb = c->h_out[q];
             if (out.quantized) {
-                HIPCHK(c, hipMemcpyAsync(hb, c->d_img[k & 1], (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->copy_stream));
-                HIPCHK(c, hipMemcpyAsync(hb + (size_t)p.nb * plane, c->d_img[k & 1] + (size_t)c->img_slots * plane,
-                                         (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->copy_stream));
+                HIPCHK(c, hipMemcpyAsync(hb, c->d_img[q], (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->d2h_stream));
+                HIPCHK(c, hipMemcpyAsync(hb + (size_t)p.nb * plane, c->d_img[q] + (size_t)c->img_slots * plane,
+                                         (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->d2h_stream));
             } else {
-                HIPCHK(c, hipMemcpyAsync(hb, c->d_flow_out[k & 1], (size_t)p.nb * plane * 8, hipMemcpyDeviceToHost,
-                                         c->copy_stream));
+                HIPCHK(c, hipMemcpyAsync(hb, c->d_flow_out[q], (size_t)p.nb * plane * 8, hipMemcpyDeviceToHost,
+                                         c->d2h_stream));
             }
-            HIPCHK(c, hipEventRecord(c->ev_d2h[k & 1], c->copy_stream));
+            HIPCHK(c, hipEventRecord(c->ev_d2h[q], c->d2h_stream));
             return DFX_OK;
         }
         for (int j = 0; j < p.nb; ++j) {
             if (out.quantized) {
-                const unsigned char *sx = c->d_img[k & 1] + (size_t)j * plane;
-                const unsigned char *sy = c->d_img[k & 1] + ((size_t)c->img_slots + j) * plane;
+                const unsigned char *sx = c->d_img[q] + (size_t)j * plane;
+                const unsigned char *sy = c->d_img[q] + ((size_t)c->img_slots + j) * plane;
                 HIPCHK(c, copy_rows_async(out.img_x[p.i0 + j], out.img_pitch, sx, c->W, c->W, c->H,
-                                          hipMemcpyDeviceToHost, c->copy_stream));
+                                          hipMemcpyDeviceToHost, c->d2h_stream));
                 HIPCHK(c, copy_rows_async(out.img_y[p.i0 + j], out.img_pitch, sy, c->W, c->W, c->H,
-                                          hipMemcpyDeviceToHost, c->copy_stream));
+                                          hipMemcpyDeviceToHost, c->d2h_stream));
             } else {
-                HIPCHK(c, copy_rows_async(out.flows[p.i0 + j], out.out_pitch, c->d_flow_out[k & 1] + (size_t)j * plane * 2,
+                HIPCHK(c, copy_rows_async(out.flows[p.i0 + j], out.out_pitch, c->d_flow_out[q] + (size_t)j * plane * 2,
                                           (size_t)c->W * 8, (size_t)c->W * 8, c->H, hipMemcpyDeviceToHost,
-                                          c->copy_stream));
+                                          c->d2h_stream));
             }
         }
-        HIPCHK(c, hipEventRecord(c->ev_d2h[k & 1], c->copy_stream));
+        HIPCHK(c, hipEventRecord(c->ev_d2h[q], c->d2h_stream));
         return DFX_OK;
     };
 
@@ -292,8 +348,8 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     };
     auto scatter = [&](size_t k) -> int { // bounce mode: results of batch k -> the caller's buffers (host memcpy)
         const BatchPlan &p = plan[k];
-        HIPCHK(c, hipEventSynchronize(c->ev_d2h[k & 1]));
-        const unsigned char *hb = c->h_out[k & 1];
+        HIPCHK(c, hipEventSynchronize(c->ev_d2h[par(k)]));
+        const unsigned char *hb = c->h_out[par(k)];
         for (int j = 0; j < p.nb; ++j) {
             if (out.quantized) {
                 copy_rows(out.img_x[p.i0 + j], out.img_pitch, hb + (size_t)j * plane, c->W, c->H);
@@ -313,9 +369,8 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     for (size_t k = 0; k < plan.size(); ++k) {
         const BatchPlan &p = plan[k];
         if (host_mode) {
-            // copy stream, in order: flows of batch k-1 down (after its compute), frames of batch k+1 up.
-            // Staging set (k+1)&1 was last read by batch k-1's frame preparation, which the download just
-            // enqueued already waits for.
+            // flows of batch k-1 down (download stream, after its compute), frames of batch k+1 up (upload stream,
+            // after the frame preparation of batch k-1, which last read that staging set)
             if (k >= 1) {
                 rc = download(k - 1);
                 if (rc != DFX_OK)
@@ -326,9 +381,9 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 if (rc != DFX_OK)
                     return rc;
             }
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d[k & 1], 0));
-            if (k >= 2) // flow staging set k&1 must have been drained by the download of batch k-2
-                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2h[k & 1], 0));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d[par(k)], 0));
+            if (seq0 + k >= 2) // flow staging set par(k) must have been drained by the download of batch q-2
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_d2h[par(k)], 0));
         }
         HIPCHK(c, hipEventRecord(c->ev_t0, c->stream));
         for (int j = 0; j < p.n_new; ++j)
@@ -336,18 +391,18 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         if (p.n_new > 0) {
             if (prep) { // cvtColor + cv::resize of load_frames_batch (src/denseflow_gpu.cpp:163, :169), on the device
                 if (host_mode)
-                    prepare_launch(c->stream, c->d_src[k & 1], (long long)c->in_row_bytes(),
+                    prepare_launch(c->stream, c->d_src[par(k)], (long long)c->in_row_bytes(),
                                    (long long)c->src_frame_bytes, c->src_w, c->src_h, c->src_ch, p.n_new,
-                                   c->d_u8[k & 1], c->W, (long long)plane, c->W, c->H);
+                                   c->d_u8[par(k)], c->W, (long long)plane, c->W, c->H);
                 else
                     prepare_launch(c->stream, d_frames + (size_t)p.first_new * d_frame_stride, (long long)d_pitch,
-                                   (long long)d_frame_stride, c->src_w, c->src_h, c->src_ch, p.n_new, c->d_u8[k & 1],
+                                   (long long)d_frame_stride, c->src_w, c->src_h, c->src_ch, p.n_new, c->d_u8[par(k)],
                                    c->W, (long long)plane, c->W, c->H);
                 HIPCHK(c, hipGetLastError());
                 c->stats.kernel_launches += 1;
             }
             if (host_mode || prep)
-                rc = E->build_frames(c->d_u8[k & 1], (long long)c->W * c->H, c->W, p.n_new, c->h_slots.data());
+                rc = E->build_frames(c->d_u8[par(k)], (long long)c->W * c->H, c->W, p.n_new, c->h_slots.data());
             else
                 rc = E->build_frames(d_frames + (size_t)p.first_new * d_frame_stride, (long long)d_frame_stride,
                                      (long long)d_pitch, p.n_new, c->h_slots.data());
@@ -363,15 +418,15 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             c->h_pairs[j].frame_b = b % F;
         }
         const bool staged = host_mode || out.quantized;
-        float *dst = staged ? c->d_flow_out[k & 1] : out.d_flows + (size_t)p.i0 * out.d_flow_stride;
+        float *dst = staged ? c->d_flow_out[par(k)] : out.d_flows + (size_t)p.i0 * out.d_flow_stride;
         const long long dst_stride = staged ? (long long)plane * 2 : (long long)out.d_flow_stride;
         rc = E->run_pairs(p.nb, c->h_pairs.data(), dst, dst_stride);
         if (rc != DFX_OK)
             return rc;
         if (out.quantized) { // convertFlowToImage on the device (src/common.cpp:4-16)
             if (host_mode)
-                quant_launch_flow_to_u8(c->stream, dst, dst_stride, p.nb, c->W, c->H, out.lo, out.hi, c->d_img[k & 1],
-                                        c->d_img[k & 1] + (size_t)c->img_slots * plane, c->W, (long long)plane);
+                quant_launch_flow_to_u8(c->stream, dst, dst_stride, p.nb, c->W, c->H, out.lo, out.hi, c->d_img[par(k)],
+                                        c->d_img[par(k)] + (size_t)c->img_slots * plane, c->W, (long long)plane);
             else
                 quant_launch_flow_to_u8(c->stream, dst, dst_stride, p.nb, c->W, c->H, out.lo, out.hi,
                                         out.d_img_x + (size_t)p.i0 * out.d_img_stride,
@@ -381,8 +436,7 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             c->stats.kernel_launches += 1;
         }
         HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
-        if (host_mode)
-            HIPCHK(c, hipEventRecord(c->ev_compute[k & 1], c->stream));
+        HIPCHK(c, hipEventRecord(c->ev_compute[par(k)], c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream)); // the engines' statistics read-backs are complete
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
@@ -397,17 +451,82 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         }
     }
     if (host_mode) {
-        rc = download(plan.size() - 1);
+        const size_t last = plan.size() - 1;
+        rc = download(last);
         if (rc != DFX_OK)
             return rc;
-        HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+        if (ticket) {
+            // deferred tail: wait for the last download and hand its rows over on a helper thread, so that the
+            // caller can issue the next FlowBuffer now (its uploads run on the other copy stream)
+            std::unique_ptr<dfx_context::Tail> t(new dfx_context::Tail());
+            t->ticket = c->next_ticket++;
+            t->parity = par(last);
+            dfx_context::Tail *tp = t.get();
+            const BatchPlan lp = plan[last];
+            hipEvent_t ev = c->ev_d2h[par(last)];
+            const unsigned char *hb = bounce ? c->h_out[par(last)] : nullptr;
+            const int W = c->W, H = c->H, dev = c->device;
+            // the caller's pointer arrays need not outlive the submit call: copy the last batch's entries
+            std::vector<void *> dst_a, dst_b;
+            for (int j = 0; bounce && j < lp.nb; ++j) {
+                if (out.quantized) {
+                    dst_a.push_back(out.img_x[lp.i0 + j]);
+                    dst_b.push_back(out.img_y[lp.i0 + j]);
+                } else {
+                    dst_a.push_back(out.flows[lp.i0 + j]);
+                }
+            }
+            const bool quant = out.quantized;
+            const size_t dpitch = quant ? out.img_pitch : out.out_pitch;
+            t->worker = std::thread([=]() {
+                (void)hipSetDevice(dev);
+                const hipError_t e = hipEventSynchronize(ev);
+                if (e != hipSuccess) {
+                    tp->rc = DFX_ERR_HIP;
+                    tp->err = std::string("deferred download failed: ") + hipGetErrorString(e);
+                    return;
+                }
+                if (!hb)
+                    return;
+                const size_t pl = (size_t)W * H;
+                for (int j = 0; j < lp.nb; ++j) {
+                    if (quant) {
+                        copy_rows(dst_a[j], dpitch, hb + (size_t)j * pl, (size_t)W, H);
+                        copy_rows(dst_b[j], dpitch, hb + ((size_t)lp.nb + j) * pl, (size_t)W, H);
+                    } else {
+                        copy_rows(dst_a[j], dpitch, hb + (size_t)j * pl * 8, (size_t)W * 8, H);
+                    }
+                }
+            });
+            *ticket = t->ticket;
+            c->tails.push_back(std::move(t));
+            return DFX_OK;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->d2h_stream));
         if (bounce) {
-            rc = scatter(plan.size() - 1);
+            rc = scatter(last);
             if (rc != DFX_OK)
                 return rc;
         }
     }
     return DFX_OK;
+}
+
+// An error return may leave asynchronous copies in flight that target caller-owned (often pool-recycled) buffers:
+// drain every stream and every deferred tail before handing the error back.
+int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_pitch, const uint8_t *d_frames,
+                    size_t d_pitch, size_t d_frame_stride, int n_frames, int step, const OutSpec &out,
+                    unsigned long long *ticket = nullptr) {
+    const int rc = calc_batch_body(c, frames, frame_pitch, d_frames, d_pitch, d_frame_stride, n_frames, step, out, ticket);
+    if (rc != DFX_OK) {
+        const std::string keep = c->err;
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->d2h_stream);
+        (void)dfx_finish_tails(c, 0, -1);
+        c->err = keep;
+    }
+    return rc;
 }
 
 } // namespace
@@ -492,6 +611,7 @@ int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height
         HIPCHK(c, hipSetDevice(device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
         for (auto &e : c->ev_h2d)
             HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : c->ev_compute)
@@ -594,6 +714,57 @@ int dfx_calc_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame_p
     return calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, out);
 }
 
+int dfx_submit_batch(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
+                     float *const *flows_uv, size_t out_pitch, uint64_t *ticket) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    if (!ticket)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL ticket");
+    const int M = std::max(n_frames - std::abs(step), 0);
+    if (M > 0 && (!frames || !flows_uv))
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or flows array");
+    if (M > 0 && (frame_pitch < h->in_row_bytes() || out_pitch < (size_t)h->W * 8))
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
+    OutSpec out;
+    out.flows = flows_uv;
+    out.out_pitch = out_pitch;
+    unsigned long long t = 0;
+    const int rc = calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, out, &t);
+    *ticket = t;
+    return rc;
+}
+
+int dfx_submit_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
+                        double lower_bound, double upper_bound, uint8_t *const *img_x, uint8_t *const *img_y,
+                        size_t img_pitch, uint64_t *ticket) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    if (!ticket)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL ticket");
+    const int M = std::max(n_frames - std::abs(step), 0);
+    if (M > 0 && (!frames || !img_x || !img_y))
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or image plane array");
+    if (M > 0 && (frame_pitch < h->in_row_bytes() || img_pitch < (size_t)h->W))
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
+    OutSpec out;
+    out.quantized = true;
+    out.lo = lower_bound;
+    out.hi = upper_bound;
+    out.img_x = img_x;
+    out.img_y = img_y;
+    out.img_pitch = img_pitch;
+    unsigned long long t = 0;
+    const int rc = calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, out, &t);
+    *ticket = t;
+    return rc;
+}
+
+int dfx_wait(dfx_handle h, uint64_t ticket) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    return dfx_finish_tails(h, ticket, -1);
+}
+
 int dfx_calc_batch_u8_device(dfx_handle h, const uint8_t *d_frames, size_t pitch, size_t frame_stride, int n_frames,
                              int step, double lower_bound, double upper_bound, uint8_t *d_img_x, uint8_t *d_img_y,
                              size_t img_pitch, size_t img_stride) {
@@ -621,6 +792,7 @@ int dfx_flow_to_u8_device(dfx_handle h, const float *d_flows, size_t flow_stride
                           size_t img_stride) {
     if (!h)
         return DFX_ERR_INVALID;
+    (void)dfx_finish_tails(h, 0, -1);
     if (n < 0)
         return dfx_fail(h, DFX_ERR_INVALID, "n must be >= 0");
     if (n == 0)
@@ -666,6 +838,7 @@ int dfx_prepare_frames_device(dfx_handle h, const uint8_t *d_src, size_t src_pit
                               size_t gray_frame_stride) {
     if (!h)
         return DFX_ERR_INVALID;
+    (void)dfx_finish_tails(h, 0, -1);
     if (n < 0)
         return dfx_fail(h, DFX_ERR_INVALID, "n must be >= 0");
     if (n == 0)
@@ -689,6 +862,7 @@ int dfx_prepare_frames(dfx_handle h, const uint8_t *const *src, size_t src_pitch
                        int channels, int n, uint8_t *const *gray, size_t gray_pitch) {
     if (!h)
         return DFX_ERR_INVALID;
+    (void)dfx_finish_tails(h, 0, -1);
     if (n < 0)
         return dfx_fail(h, DFX_ERR_INVALID, "n must be >= 0");
     if (n == 0)
@@ -746,8 +920,11 @@ void dfx_destroy(dfx_handle h) {
     if (!h)
         return;
     (void)hipSetDevice(h->device);
+    (void)dfx_finish_tails(h, 0, -1);
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
+    if (h->d2h_stream)
+        (void)hipStreamSynchronize(h->d2h_stream);
     delete h->engine;
     h->engine = nullptr;
     if (h->copy_stream)
@@ -775,6 +952,8 @@ void dfx_destroy(dfx_handle h) {
             (void)hipEventDestroy(e);
     if (h->copy_stream)
         (void)hipStreamDestroy(h->copy_stream);
+    if (h->d2h_stream)
+        (void)hipStreamDestroy(h->d2h_stream);
     if (h->ev_t0)
         (void)hipEventDestroy(h->ev_t0);
     if (h->ev_t1)

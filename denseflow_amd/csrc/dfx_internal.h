@@ -6,7 +6,10 @@
 
 #include <cmath>
 #include <cstdio>
+#include <deque>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dfx.h"
@@ -47,7 +50,8 @@ struct dfx_context {
     size_t in_row_bytes() const { return (size_t)in_w() * (prepares() ? src_ch : 1); }
 
     hipStream_t stream = nullptr;      // compute
-    hipStream_t copy_stream = nullptr; // host <-> device copies of the host-pointer entry points
+    hipStream_t copy_stream = nullptr; // host -> device copies of the host-pointer entry points
+    hipStream_t d2h_stream = nullptr;  // device -> host copies: uploads of the next batch / FlowBuffer overlap them
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};     // frames of batch i are in staging set i&1
     hipEvent_t ev_compute[2] = {nullptr, nullptr}; // flows of batch i are in staging set i&1
@@ -73,7 +77,25 @@ struct dfx_context {
     std::vector<PairDesc> h_pairs; // descriptors of the current batch
 
     dfx_stats stats{};
+
+    // Batches are numbered across calls: staging set, bounce buffer and event of batch q are those of parity q & 1.
+    unsigned long long batch_seq = 0;
+    // Deferred tails of dfx_submit_*: the last download of a FlowBuffer (and, for small frames, the hand-over from
+    // the bounce buffer to the caller's buffers) completes on a helper thread while the next FlowBuffer is issued.
+    struct Tail {
+        unsigned long long ticket = 0;
+        int parity = 0;
+        int rc = DFX_OK;
+        std::string err;
+        std::thread worker;
+    };
+    std::deque<std::unique_ptr<Tail>> tails;
+    unsigned long long next_ticket = 1;
 };
+
+// Join the deferred tails with ticket <= up_to (0 = all) / of staging parity `parity` (-1 = any).  Returns the first
+// error a tail met.
+int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity);
 
 #define HIPCHK(ctx, call)                                                                                       \
     do {                                                                                                        \

@@ -151,6 +151,13 @@ def load_library():
     L.dfx_calc_batch_device.restype = i
     L.dfx_calc_batch_u8.argtypes = [vp, C.POINTER(vp), sz, i, i, C.c_double, C.c_double, C.POINTER(vp), C.POINTER(vp), sz]
     L.dfx_calc_batch_u8.restype = i
+    L.dfx_submit_batch.argtypes = [vp, C.POINTER(vp), sz, i, i, C.POINTER(vp), sz, C.POINTER(C.c_uint64)]
+    L.dfx_submit_batch.restype = i
+    L.dfx_submit_batch_u8.argtypes = [vp, C.POINTER(vp), sz, i, i, C.c_double, C.c_double, C.POINTER(vp), C.POINTER(vp),
+                                      sz, C.POINTER(C.c_uint64)]
+    L.dfx_submit_batch_u8.restype = i
+    L.dfx_wait.argtypes = [vp, C.c_uint64]
+    L.dfx_wait.restype = i
     L.dfx_calc_batch_u8_device.argtypes = [vp, vp, sz, sz, i, i, C.c_double, C.c_double, vp, vp, sz, sz]
     L.dfx_calc_batch_u8_device.restype = i
     L.dfx_flow_to_u8_device.argtypes = [vp, vp, sz, i, C.c_double, C.c_double, vp, vp, sz, sz]
@@ -309,6 +316,36 @@ class FlowEngine:
         op = (C.c_void_p * m)(*[f.ctypes.data for f in flows])
         self._check(self._L.dfx_calc_batch(self._h, fp, frames[0].strides[0], n, int(step), op, self.width * 8))
         return flows
+
+    # -- asynchronous FlowBuffers (dfx_submit_batch* / dfx_wait) -----------------------------------------------
+    def submit_optflows(self, frames_gray, step: int, bound: float | None = None):
+        """dfx_submit_batch (bound None: float flows) or dfx_submit_batch_u8 (planes bounded to [-bound, bound]).
+        Returns (ticket, outputs); the outputs are valid after wait(ticket).  The output arrays are created here and
+        must be kept alive by the caller until then."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
+        n = len(frames)
+        m = max(n - abs(step), 0)
+        for f in frames:
+            if f.shape != self._frame_shape():
+                raise ValueError("frame shape does not match the engine")
+        t = C.c_uint64(0)
+        fp = (C.c_void_p * max(n, 1))(*[f.ctypes.data for f in frames])
+        pitch = frames[0].strides[0] if n else self.width
+        if bound is None:
+            flows = [np.empty((self.height, self.width, 2), dtype=np.float32) for _ in range(m)]
+            op = (C.c_void_p * max(m, 1))(*[f.ctypes.data for f in flows])
+            self._check(self._L.dfx_submit_batch(self._h, fp, pitch, n, int(step), op, self.width * 8, C.byref(t)))
+            return t.value, flows
+        img_x = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
+        img_y = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
+        xp = (C.c_void_p * max(m, 1))(*[f.ctypes.data for f in img_x])
+        yp = (C.c_void_p * max(m, 1))(*[f.ctypes.data for f in img_y])
+        self._check(self._L.dfx_submit_batch_u8(self._h, fp, pitch, n, int(step), -float(bound), float(bound), xp, yp,
+                                                self.width, C.byref(t)))
+        return t.value, (img_x, img_y)
+
+    def wait(self, ticket: int = 0):
+        self._check(self._L.dfx_wait(self._h, int(ticket)))
 
     def calc_optflows_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,
                              d_flows_ptr: int, flow_stride_floats: int):

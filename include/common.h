@@ -80,6 +80,16 @@ class Mat {
     std::shared_ptr<uchar> buf_;
 };
 
+// Stand-in for cv::cuda::Stream in the reference's signatures (include/dense_flow.h:33, :58-59).  The HIP streams
+// live inside the engine handle (include/dfx.h); this type only keeps the reference's API shape.
+class Stream {
+  public:
+    static Stream &Null() {
+        static Stream s;
+        return s;
+    }
+};
+
 void split(const Mat &flow, Mat planes[2]); // CV_32FC2 -> two CV_32FC1 (reference: cv::split, :418)
 
 void convertFlowToImage(const Mat &flow_x, const Mat &flow_y, Mat &img_x, Mat &img_y, double lowerBound,

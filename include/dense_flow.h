@@ -49,6 +49,7 @@ class FlowBufferQueue {
     FlowBuffer pop(bool *was_final);
     // a stage died: producers stop blocking, consumers see an empty final buffer
     void close();
+    size_t size();
 
   private:
     size_t maxsize_;
@@ -92,6 +93,16 @@ class DenseFlow {
     // the device engine (replaces Ptr<cuda::*OpticalFlow> + cv::cuda::Stream)
     dfx_handle dfx_;
     Size dfx_size_;
+    Stream stream; // reference member (include/dense_flow.h:33)
+    // the FlowBuffer whose last download is still in flight (dfx_submit_batch*), and whether the buffer being
+    // processed is the last of the run
+    struct PendingFlows {
+        FlowBuffer flows;
+        uint64_t ticket;
+        bool is_final;
+    };
+    std::unique_ptr<PendingFlows> pending_;
+    bool flows_final_ = false;
 
     bool check_param();
     bool get_new_size(const VideoCapture &video_stream, const vector<path> &frames_path, bool use_frames,
@@ -100,8 +111,10 @@ class DenseFlow {
                            vector<Mat> &frames_gray, bool do_resize, const Size &size, bool to_gray);
     int load_frames_video(VideoCapture &video_stream, vector<path> &frames_path, bool use_frames, bool do_resize,
                           const Size &size, path output_dir, bool is_last, bool verbose);
+    // the reference's signature (include/dense_flow.h:58-59); `stream` is a tag here, the engine owns its HIP streams
     void calc_optflows_imp(const FlowBuffer &frames_gray, const string &algorithm, int step, bool verbose,
-                           bool is_final);
+                           Stream &stream = Stream::Null());
+    void flush_pending();
     void load_frames(bool use_frames, string save_type, bool verbose = true);
     void calc_optflows(bool verbose = true);
     void encode_save(string save_type, bool verbose = true);

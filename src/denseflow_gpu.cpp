@@ -49,6 +49,11 @@ void FlowBufferQueue::close() {
     not_empty_.notify_all();
 }
 
+size_t FlowBufferQueue::size() {
+    unique_lock<mutex> lock(mtx_);
+    return q_.size();
+}
+
 FlowBuffer FlowBufferQueue::pop(bool *was_final) {
     unique_lock<mutex> lock(mtx_);
     not_empty_.wait(lock, [&] { return closed_ || !q_.empty(); });
@@ -276,12 +281,29 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
 
 // ------------------------------------------------------------------------------------------------ the hot path
 
-// One FlowBuffer of gray frames -> M = max(N - |step|, 0) flows, on the GPU.
+// Results of the previous FlowBuffer whose last download is still in flight (dfx_submit_batch*): hand them to the
+// save stage now.
+void DenseFlow::flush_pending() {
+    if (!pending_)
+        return;
+    if (pending_->ticket && dfx_ && dfx_wait(dfx_, pending_->ticket) != DFX_OK)
+        throw std::runtime_error(dfx_last_error(dfx_));
+    flows_queue.push(std::move(pending_->flows), pending_->is_final);
+    pending_.reset();
+}
+
+// One FlowBuffer of gray frames -> M = max(N - |step|, 0) flows, on the GPU (reference :282-370).  The `stream`
+// argument is the reference's (include/dense_flow.h:58-59); the engine owns its HIP streams, so it is only a tag here.
+// The FlowBuffer is SUBMITTED: its last download overlaps the next FlowBuffer's uploads and compute, and its flows are
+// pushed to the save stage when the next call (or the end of input) collects them.
 void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &algorithm, int step, bool verbose,
-                                  bool is_final) {
+                                  Stream &stream) {
+    (void)stream;
+    const bool is_final = flows_final_;
     const int N = (int)frames_gray.item_data.size();
     const int M = std::max(N - std::abs(step), 0);
     vector<Mat> flows(M);
+    uint64_t ticket = 0;
     if (M > 0) {
         dfx_algo algo;
         const int rc = dfx_algo_from_name(algorithm.c_str(), &algo);
@@ -291,8 +313,19 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
         }
         const Size in_sz = frames_gray.item_data[0].size();
         const Size sz = frames_gray.target.width > 0 ? frames_gray.target : in_sz; // size of the flows
+        // One pitch and one source format describe the whole FlowBuffer: every frame must have the first one's
+        // geometry (the reference resizes frame by frame, :166-170, so mixed-size image directories work there;
+        // here they would be read out of bounds).
+        for (int i = 1; i < N; ++i) {
+            const Mat &f = frames_gray.item_data[i];
+            if (!(f.size() == in_sz) || f.step != frames_gray.item_data[0].step || f.type() != CV_8UC1)
+                throw std::runtime_error("frames of one FlowBuffer differ in size (" + std::to_string(f.cols) + "x" +
+                                         std::to_string(f.rows) + " after " + std::to_string(in_sz.width) + "x" +
+                                         std::to_string(in_sz.height) + ")");
+        }
         TRACE("calc: %d frames -> %d flows, %dx%d, algorithm %s", N, M, sz.width, sz.height, algorithm.c_str());
         if (!dfx_ || !(sz == dfx_size_)) { // sized per video; reused across its FlowBuffers
+            flush_pending();
             if (dfx_)
                 dfx_destroy(dfx_);
             dfx_ = nullptr;
@@ -317,8 +350,8 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
                 out_x[i] = flows[2 * i].ptr<uint8_t>();
                 out_y[i] = flows[2 * i + 1].ptr<uint8_t>();
             }
-            if (dfx_calc_batch_u8(dfx_, in.data(), frames_gray.item_data[0].step, N, step, -bound, bound, out_x.data(),
-                                  out_y.data(), flows[0].step) != DFX_OK)
+            if (dfx_submit_batch_u8(dfx_, in.data(), frames_gray.item_data[0].step, N, step, -bound, bound,
+                                    out_x.data(), out_y.data(), flows[0].step, &ticket) != DFX_OK)
                 throw std::runtime_error(dfx_last_error(dfx_));
         } else {
             vector<float *> out(M);
@@ -326,25 +359,30 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
                 flows[i].create(sz, CV_32FC2);
                 out[i] = flows[i].ptr<float>();
             }
-            if (dfx_calc_batch(dfx_, in.data(), frames_gray.item_data[0].step, N, step, out.data(), flows[0].step) !=
-                DFX_OK)
+            if (dfx_submit_batch(dfx_, in.data(), frames_gray.item_data[0].step, N, step, out.data(), flows[0].step,
+                                 &ticket) != DFX_OK)
                 throw std::runtime_error(dfx_last_error(dfx_));
         }
-        TRACE("calc: dfx_calc_batch done");
+        TRACE("calc: FlowBuffer submitted, ticket %llu", (unsigned long long)ticket);
         total_flows += M;
     }
     if (verbose)
         cout << "flows queue push a item" << endl;
-    flows_queue.push(FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start, frames_gray.last_buffer,
-                                device_bounding && M > 0),
-                     is_final);
+    flush_pending(); // the previous FlowBuffer's tail ran beside this one's uploads and compute
+    pending_.reset(new PendingFlows{FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start,
+                                               frames_gray.last_buffer, device_bounding && M > 0),
+                                    ticket, is_final});
+    // nothing queued behind this buffer (or the end of input): holding it back would gain nothing
+    if (is_final || frames_gray_queue.size() == 0)
+        flush_pending();
 }
 
 void DenseFlow::calc_optflows(bool verbose) {
     while (true) {
         bool is_final = false;
         FlowBuffer frames_gray = frames_gray_queue.pop(&is_final);
-        calc_optflows_imp(frames_gray, algorithm, step, false, is_final);
+        flows_final_ = is_final;
+        calc_optflows_imp(frames_gray, algorithm, step, false, stream);
         if (is_final)
             break;
     }
@@ -501,7 +539,8 @@ void DenseFlow::launch(bool use_frames, string save_type, bool verbose) {
 vector<Mat> DenseFlowTestAccess::run_calc_optflows_imp(DenseFlow &d, const vector<Mat> &frames_gray,
                                                         const string &algorithm, int step, bool bounded) {
     d.device_bounding = bounded;
-    d.calc_optflows_imp(FlowBuffer(frames_gray, path(), 0, true), algorithm, step, false, true);
+    d.flows_final_ = true;
+    d.calc_optflows_imp(FlowBuffer(frames_gray, path(), 0, true), algorithm, step, false, d.stream);
     bool fin = false;
     return d.flows_queue.pop(&fin).item_data;
 }
