@@ -85,6 +85,14 @@ class DenseFlow {
     bool device_resize;
 
     int batch_maxsize;
+    // Level-2 sharding: this pipeline computes flows [begin, end) of every video, the contiguous
+    // range of shard `shard_rank` of `shard_world`; output indices stay global through base_start.  Frames
+    // [begin, end + |step|) are loaded — the |step| overlap frames the reference's own batch padding duplicates
+    // (src/denseflow_gpu.cpp:204-208).  world 1 = the whole video.
+    int shard_rank = 0, shard_world = 1;
+    long frames_budget = -1; // frames the loader may still read from the current video (-1: to its end)
+    int flow_begin_ = 0;     // global index of the first flow this pipeline computes in the current video
+    int src_w_ = 0, src_h_ = 0; // size of the current video's decoded frames (get_new_size)
     FlowBufferQueue frames_gray_queue;
     FlowBufferQueue flows_queue;
     unsigned long total_frames;
@@ -124,6 +132,12 @@ class DenseFlow {
 
   public:
     void launch(bool use_frames, string save_type, bool verbose);
+    void set_shard(int rank, int world) {
+        shard_rank = rank;
+        shard_world = world;
+    }
+    // flows [begin, end) of a clip of n_frames frames that shard `rank` of `world` computes (contiguous, balanced)
+    static void shard_range(int n_frames, int step, int rank, int world, int &begin, int &end);
     void extract_frames_only(bool use_frames, bool verbose);
     unsigned long get_processed_total_frames() { return total_frames; }
     unsigned long get_processed_total_flows() { return total_flows; }

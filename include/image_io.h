@@ -17,11 +17,13 @@ class VideoCapture {
     int height() const { return h_; }
     int frameCount() const { return frames_; } // -1 when unknown
     bool read(Mat &gray);                      // false at end of stream
+    bool seekFrame(int index);                 // the next read() returns frame `index` (frames without parameters)
 
   private:
     std::shared_ptr<FILE> f_;
     int w_ = 0, h_ = 0, frames_ = -1;
     size_t chroma_bytes_ = 0;
+    long data_start_ = 0;
 };
 
 bool imreadGray(const string &file, Mat &gray);          // .pgm (P5) / .ppm (P6, BGR2GRAY fixed-point weights)

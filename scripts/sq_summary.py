@@ -17,9 +17,10 @@ def main():
     grid = {}
     for f in files:
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
-            if not any(p in k for p in pats):
+            full = r["Kernel_Name"]
+            if not any(p in full for p in pats):
                 continue
+            k = full.replace("(anonymous namespace)::", "").split("(")[0]
             a = agg[k][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])

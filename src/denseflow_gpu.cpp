@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <cmath>
 
 #include "utils.h"
@@ -140,6 +141,8 @@ bool DenseFlow::get_new_size(const VideoCapture &video_stream, const vector<path
         height = video_stream.height();
         frames_num = video_stream.frameCount();
     }
+    src_w_ = width; // with the resize on the device the loader queues SOURCE-size frames: buffers are sized from these
+    src_h_ = height;
     bool do_resize = true;
     if (new_width > 0 && new_height > 0) {
         new_size = Size(new_width, new_height);
@@ -179,6 +182,8 @@ bool DenseFlow::load_frames_batch(VideoCapture &video_stream, const vector<path>
     int cnt = 0;
     while (cnt < batch_maxsize) {
         Mat frame;
+        if (frames_budget == 0) // this pipeline's shard of the video ends here
+            return false;
         if (use_frames) {
             if (cnt == (int)frames_path.size())
                 return false;
@@ -195,13 +200,22 @@ bool DenseFlow::load_frames_batch(VideoCapture &video_stream, const vector<path>
             frames_gray.push_back(frame);
         }
         cnt++;
+        if (frames_budget > 0)
+            --frames_budget;
     }
     return true;
 }
 
+void DenseFlow::shard_range(int n_frames, int step, int rank, int world, int &begin, int &end) {
+    const int m = std::max(n_frames - std::abs(step), 0);
+    const int base = m / world, extra = m % world;
+    begin = rank * base + std::min(rank, extra);
+    end = begin + base + (rank < extra ? 1 : 0);
+}
+
 int DenseFlow::load_frames_video(VideoCapture &video_stream, vector<path> &frames_path, bool use_frames,
                                  bool do_resize, const Size &size, path output_dir, bool is_last, bool verbose) {
-    int video_flow_idx = 0;
+    int video_flow_idx = flow_begin_; // 0 unless this pipeline works on a shard of the video
     const int astep = std::abs(step);
     vector<Mat> padding;
     while (true) {
@@ -229,7 +243,7 @@ int DenseFlow::load_frames_video(VideoCapture &video_stream, vector<path> &frame
         if (use_frames)
             frames_path.erase(frames_path.begin(), frames_path.begin() + std::min(frames_gray.size(), frames_path.size()));
     }
-    return video_flow_idx + astep;
+    return video_flow_idx - flow_begin_ + astep;
 }
 
 void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
@@ -254,12 +268,33 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
         Size size;
         int frames_num;
         const bool do_resize = get_new_size(video_stream, frames_path, use_frames, size, frames_num);
+        flow_begin_ = 0;
+        frames_budget = -1;
+        if (shard_world > 1) { // Level-2 sharding: only this pipeline's contiguous range of the video's flows
+            if (frames_num < 0)
+                throw std::runtime_error("cannot shard a stream of unknown length: " + video_path.string());
+            int fb, fe;
+            shard_range(frames_num, step, shard_rank, shard_world, fb, fe);
+            const bool is_last_video = i == video_paths.size() - 1;
+            if (fe == fb) { // fewer flows than shards: nothing to do here
+                if (is_last_video) {
+                    frames_gray_queue.push(FlowBuffer({}, path(), 0, false), true);
+                    final_pushed = true;
+                }
+                continue;
+            }
+            flow_begin_ = fb;
+            frames_budget = (long)(fe - fb) + std::abs(step);
+            if (use_frames)
+                frames_path.erase(frames_path.begin(), frames_path.begin() + fb);
+            else if (!video_stream.seekFrame(fb))
+                throw std::runtime_error("cannot seek in " + video_path.string());
+        }
         // Frames per FlowBuffer.  The reference fixes 512 (include/dense_flow.h:33); the three stages only
         // overlap across buffers, so large frames get shorter buffers (2 device batches each): 128 frames at
         // 1080p, 512 from 724x724 down.  Buffer boundaries do not change any flow (the last |step| frames
         // are carried over, :204-207).
-        const long long frame_px = std::max((long long)size.width * size.height,
-                                            use_frames ? 0ll : (long long)video_stream.width() * video_stream.height());
+        const long long frame_px = std::max((long long)size.width * size.height, (long long)src_w_ * src_h_);
         batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, (256ll << 20) / std::max(1ll, frame_px)));
         if (const char *bm = std::getenv("DF_BATCH_MAXSIZE")) // testing aid: force short buffers
             batch_maxsize = std::max(1, std::atoi(bm));
@@ -372,8 +407,10 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
     pending_.reset(new PendingFlows{FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start,
                                                frames_gray.last_buffer, device_bounding && M > 0),
                                     ticket, is_final});
-    // nothing queued behind this buffer (or the end of input): holding it back would gain nothing
-    if (is_final || frames_gray_queue.size() == 0)
+    // nothing queued behind this buffer (or the end of input): holding it back would gain nothing.
+    // DF_SYNC_FLOW=1 (A/B measurements): collect every FlowBuffer at once, like the synchronous dfx_calc_batch*.
+    static const bool sync_flow = std::getenv("DF_SYNC_FLOW") != nullptr;
+    if (is_final || sync_flow || frames_gray_queue.size() == 0)
         flush_pending();
 }
 
@@ -391,6 +428,20 @@ void DenseFlow::calc_optflows(bool verbose) {
 }
 
 // ------------------------------------------------------------------------------------------------ encode + save
+
+// `.done/<stem>` marker + the "done video" line (reference :456-470)
+static void mark_done(const path &output_dir, bool has_class) {
+    path donedir, title;
+    if (has_class) {
+        donedir = output_dir.parent_path().parent_path() / ".done" / output_dir.parent_path().filename();
+        title = output_dir.parent_path().filename() / output_dir.filename();
+    } else {
+        donedir = output_dir.parent_path() / ".done";
+        title = output_dir.filename();
+    }
+    createFile(donedir / output_dir.stem().string());
+    cout << "done video " << title << endl;
+}
 
 void DenseFlow::encode_save(string save_type, bool verbose) {
     while (true) {
@@ -438,19 +489,8 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
             writeHDF5(output_h5_y, flow_buffer.output_dir.string(), "flow_y", step, flow_buffer.base_start);
         }
         // mark the video done after its last buffer has been written (resume support, :456-470)
-        if (is_record && flow_buffer.last_buffer) {
-            path donedir, title;
-            if (has_class) {
-                donedir = flow_buffer.output_dir.parent_path().parent_path() / ".done" /
-                          flow_buffer.output_dir.parent_path().filename();
-                title = flow_buffer.output_dir.parent_path().filename() / flow_buffer.output_dir.filename();
-            } else {
-                donedir = flow_buffer.output_dir.parent_path() / ".done";
-                title = flow_buffer.output_dir.filename();
-            }
-            createFile(donedir / flow_buffer.output_dir.stem().string());
-            cout << "done video " << title << endl;
-        }
+        if (is_record && flow_buffer.last_buffer)
+            mark_done(flow_buffer.output_dir, has_class);
         if (is_final)
             break;
     }
@@ -484,6 +524,14 @@ int DenseFlow::extract_frames_video(VideoCapture &video_stream, vector<path> &fr
 }
 
 void DenseFlow::extract_frames_only(bool use_frames, bool verbose) {
+    // Deliberate limitation, stated loudly: the reference's -s=0 mode writes COLOUR frames (it reads BGR,
+    // src/denseflow_gpu.cpp:100-117); this decoder-free build has a gray-only JPEG encoder and reads the Y plane of
+    // .y4m clips / converts .ppm to gray, so the extracted img_%05d.jpg are single-channel.
+    static std::once_flag warned;
+    std::call_once(warned, [] {
+        cout << "note: -s=0 in this build writes GRAY frames (Y plane / BGR2GRAY); the reference writes colour frames"
+             << endl;
+    });
     for (size_t i = 0; i < video_paths.size(); i++) {
         VideoCapture video_stream;
         vector<path> frames_path;
@@ -562,17 +610,23 @@ void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_di
                                 bool use_frames, string save_type, bool is_record, bool verbose, vector<int> devices) {
     if (devices.empty())
         devices.push_back(0);
-    const size_t G = std::min(devices.size(), std::max<size_t>(video_paths.size(), 1));
-    // videos are dealt round-robin to the devices; each device runs its own three-thread pipeline
+    // Level 1: videos are dealt round-robin to the devices, each device runs its own three-thread
+    // pipeline.  Level 2: with fewer videos than devices (one long clip on an 8-GPU node) every pipeline takes a
+    // contiguous range of EVERY video's flows instead; file indices stay global, the `.done` marker is written here
+    // once all shards of a video are on disk.  (-st=h5 keeps Level 1: one writer per file.)
+    const bool split = step != 0 && save_type != "h5" && !video_paths.empty() && video_paths.size() < devices.size();
+    const size_t G = split ? devices.size() : std::min(devices.size(), std::max<size_t>(video_paths.size(), 1));
     vector<std::unique_ptr<DenseFlow>> workers;
     for (size_t g = 0; g < G; ++g) {
         vector<path> vp, od;
-        for (size_t i = g; i < video_paths.size(); i += G) {
+        for (size_t i = split ? 0 : g; i < video_paths.size(); i += split ? 1 : G) {
             vp.push_back(video_paths[i]);
             od.push_back(output_dirs[i]);
         }
         workers.emplace_back(new DenseFlow(vp, od, algorithm, step, bound, new_width, new_height, new_short, has_class,
-                                           is_record, save_type, devices[g]));
+                                           is_record && !split, save_type, devices[g]));
+        if (split)
+            workers.back()->set_shard((int)g, (int)G);
     }
     const double start_t = CurrentSeconds();
     vector<std::exception_ptr> errs(G);
@@ -593,10 +647,13 @@ void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_di
     for (auto &e : errs)
         if (e)
             std::rethrow_exception(e);
+    if (split && is_record)
+        for (const path &od : output_dirs)
+            mark_done(od, has_class);
     const double end_t = CurrentSeconds();
     unsigned long N = 0, F = 0;
     for (auto &w : workers) {
-        N += w->get_processed_total_frames();
+        N += w->get_processed_total_frames(); // split: the |step| overlap frames are counted by every shard
         F += w->get_processed_total_flows();
     }
     print_summary(video_paths.size(), N, F, algorithm, std::max(end_t - start_t, 1e-3));

@@ -55,7 +55,15 @@ bool VideoCapture::open(const string &file) {
     fseek(fp, here, SEEK_SET);
     const size_t per = 6 + (size_t)w_ * h_ + chroma_bytes_;
     frames_ = (int)((end - here) / (long)per);
+    data_start_ = here;
     return true;
+}
+
+bool VideoCapture::seekFrame(int index) {
+    if (!f_ || index < 0 || index > frames_)
+        return false;
+    const size_t per = 6 + (size_t)w_ * h_ + chroma_bytes_;
+    return fseek(f_.get(), data_start_ + (long)((size_t)index * per), SEEK_SET) == 0;
 }
 
 bool VideoCapture::read(Mat &gray) {

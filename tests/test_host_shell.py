@@ -117,6 +117,7 @@ def test_frame_extraction_mode_writes_decodable_jpegs(built, tmp_path):
     r = subprocess.run([built, str(clip), "-o=" + str(tmp_path / "out"), "-s=0"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
     assert "1 videos (3 frames, 0 tvl1 flows) processed" in r.stdout
+    assert "-s=0 in this build writes GRAY frames" in r.stdout  # the deviation from the reference is announced
     for i, fr in enumerate(frames):
         img = np.array(Image.open(tmp_path / "out" / "vid" / f"img_{i:05d}.jpg"))
         assert img.shape == fr.shape
@@ -456,11 +457,14 @@ def test_cli_h5_output_holds_the_unbounded_float_flows(built, oracle, tmp_path, 
 
 
 @pytest.mark.gpu
-def test_cli_videolist_sharded_over_device_pipelines_matches_the_oracle(built, oracle, tmp_path):
+def test_cli_videolist_sharded_over_device_pipelines_matches_the_oracle(built, harness, oracle, tmp_path):
     """BASELINE config 4 shape (a list of 224x224 clips, -a=tvl1, sharded over the GPUs of a node) at test size:
     8 clips through `-g` with two pipelines (on a 1-GPU box both on device 0, DF_DEVICES=0,0).  Every flow file of
-    every clip must be the JPEG of the ORACLE's bounded flow, exactly the bytes the shell's encoder makes of it."""
+    every clip must be the JPEG of the ORACLE's bounded flow: byte for byte what the shell's encoder (quality 95) makes
+    of the oracle's plane, and a decodable image close to it."""
     from PIL import Image
+
+    harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
 
     w, h, n, clips = 224, 224, 4, 8
     lst = tmp_path / "list.txt"
@@ -481,7 +485,40 @@ def test_cli_videolist_sharded_over_device_pipelines_matches_the_oracle(built, o
         assert (tmp_path / "out" / ".done" / f"v{c:02d}").is_file()
         for i in range(n - 1):
             for k, name in enumerate(("flow_x", "flow_y")):
-                img = np.array(Image.open(tmp_path / "out" / f"v{c:02d}" / f"{name}_{i:05d}.jpg")).astype(np.int32)
-                q = refs[c][i][k].astype(np.int32)
-                assert img.shape == q.shape
-                assert np.abs(img - q).max() <= 6 and np.abs(img - q).mean() < 0.6, (c, i, name)  # JPEG q95 of the oracle's plane
+                f = tmp_path / "out" / f"v{c:02d}" / f"{name}_{i:05d}.jpg"
+                plane = np.ascontiguousarray(refs[c][i][k])
+                buf = np.empty(plane.size * 2 + 4096, np.uint8)
+                nb = harness.hh_encode_jpeg(plane.ctypes.data, w, h, 95, buf.ctypes.data, buf.size)
+                assert nb > 0 and f.read_bytes() == buf[:nb].tobytes(), (c, i, name)
+                img = np.array(Image.open(f)).astype(np.int32)
+                assert img.shape == plane.shape and np.abs(img - plane).mean() < 0.6, (c, i, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["video", "frames"])
+@pytest.mark.parametrize("step", [1, -2, 3])
+def test_cli_level2_split_of_one_clip_over_device_pipelines(built, tmp_path, source, step):
+    """SURVEY.md §8e Level 2 (BASELINE configs 2/3/5 on a multi-GPU node): ONE clip, more devices than videos: every
+    pipeline computes a contiguous range of the clip's flows (|step| overlap frames loaded twice, as the reference pads
+    its own batches, src/denseflow_gpu.cpp:204-208) and writes them under their GLOBAL indices.  Three pipelines on one
+    GPU (DF_DEVICES=0,0,0) must produce the single pipeline's files byte for byte, `.done` included."""
+    w, h, n = 96, 72, 23
+    frames = SynthClip(w, h, 40).frames(n)
+    if source == "video":
+        src = tmp_path / "clip.y4m"
+        write_y4m(src, frames)
+        extra = []
+    else:
+        src = tmp_path / "clip"
+        _write_pgm_dir(src, frames)
+        extra = ["-if"]
+    outs = {}
+    for tag, env in (("one", {}), ("split", {"DF_DEVICES": "0,0,0", "DF_BATCH_MAXSIZE": "5"})):
+        r = subprocess.run([built, str(src), "-o=" + str(tmp_path / tag), "-a=farn", f"-s={step}", "-b=20"] + extra,
+                           capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert f"{n - abs(step)} farn flows) processed" in r.stdout, (tag, r.stdout)
+        outs[tag] = {str(p.relative_to(tmp_path / tag)): p.read_bytes()
+                     for p in sorted((tmp_path / tag).rglob("*")) if p.is_file()}
+    assert len(outs["one"]) == 2 * (n - abs(step)) + 1
+    assert outs["one"] == outs["split"]
