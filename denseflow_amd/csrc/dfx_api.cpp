@@ -53,21 +53,27 @@ void default_params(dfx_params *p) {
 
 int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity) {
     int rc = DFX_OK;
-    for (auto it = c->tails.begin(); it != c->tails.end();) {
-        dfx_context::Tail &t = **it;
-        if ((up_to == 0 || t.ticket <= up_to) && (parity < 0 || t.parity == parity)) {
-            if (t.worker.joinable())
-                t.worker.join();
-            if (t.rc != DFX_OK && rc == DFX_OK) {
-                rc = t.rc;
-                c->err = t.err;
+    for (;;) {
+        std::unique_ptr<dfx_context::Tail> t;
+        {
+            std::lock_guard<std::mutex> lock(c->tails_mtx);
+            for (auto it = c->tails.begin(); it != c->tails.end(); ++it) {
+                if ((up_to == 0 || (*it)->ticket <= up_to) && (parity < 0 || (*it)->parity == parity)) {
+                    t = std::move(*it);
+                    c->tails.erase(it);
+                    break;
+                }
             }
-            it = c->tails.erase(it);
-        } else {
-            ++it;
+        }
+        if (!t)
+            return rc;
+        if (t->worker.joinable()) // joined outside the lock: the submitting thread may be queueing the next tail
+            t->worker.join();
+        if (t->rc != DFX_OK && rc == DFX_OK) {
+            rc = t->rc;
+            c->err = t->err;
         }
     }
-    return rc;
 }
 
 namespace {
@@ -499,7 +505,10 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 }
             });
             *ticket = t->ticket;
-            c->tails.push_back(std::move(t));
+            {
+                std::lock_guard<std::mutex> lock(c->tails_mtx);
+                c->tails.push_back(std::move(t));
+            }
             return DFX_OK;
         }
         HIPCHK(c, hipStreamSynchronize(c->d2h_stream));

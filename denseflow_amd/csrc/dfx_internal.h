@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <deque>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -90,6 +91,7 @@ struct dfx_context {
         std::thread worker;
     };
     std::deque<std::unique_ptr<Tail>> tails;
+    std::mutex tails_mtx; // dfx_wait may be called from another thread than the one that submits
     unsigned long long next_ticket = 1;
 };
 

@@ -108,9 +108,17 @@ class DenseFlow {
         FlowBuffer flows;
         uint64_t ticket;
         bool is_final;
+        dfx_handle handle; // the engine the ticket belongs to (nullptr: nothing to wait for)
     };
-    std::unique_ptr<PendingFlows> pending_;
+    queue<std::unique_ptr<PendingFlows>> pending_q_; // submitted, tails not yet collected (collect_flows)
+    mutex pending_mtx_;
+    condition_variable pending_cv_;
+    int pending_inflight_ = 0;
+    bool pending_closed_ = false;
+    string pending_error_;
     bool flows_final_ = false;
+    void collect_flows();
+    void enqueue_pending(std::unique_ptr<PendingFlows> p);
 
     bool check_param();
     bool get_new_size(const VideoCapture &video_stream, const vector<path> &frames_path, bool use_frames,

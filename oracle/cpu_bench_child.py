@@ -37,17 +37,43 @@ def physical_cores(allowed):
     return [c for _, _, c in pick]
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time this container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.
+    Measured on the MI355X boxes of this pool (profiles/round2/cpu_thread_scan.log): 256 logical CPUs visible,
+    cpu.max = 16 CPUs — 16 threads give 0.54 pairs/s, 128 spinning threads 0.21 (throttled)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = int(f.read())
+        if q > 0:
+            return max(1, q // p)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     path, kind, budget = sys.argv[1], sys.argv[2], float(sys.argv[3])
     allowed = os.sched_getaffinity(0)
     cpus = physical_cores(allowed)
+    quota = cgroup_cpu_quota()
+    if quota is not None:
+        cpus = cpus[:quota]
     cap = int(os.environ.get("DFX_CPU_THREADS", "0"))
     if cap > 0:
-        cpus = cpus[:cap]
+        cpus = physical_cores(allowed)[:cap]
     os.environ["OMP_NUM_THREADS"] = str(len(cpus))
     os.environ["GOMP_CPU_AFFINITY"] = " ".join(str(c) for c in cpus)
     os.environ["OMP_PROC_BIND"] = "true"
-    os.environ.setdefault("OMP_WAIT_POLICY", "active")
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
@@ -84,7 +110,8 @@ def main():
         "runs": runs,
         "spread": (runs[2] - runs[0]) / runs[1],
         "sample": f"median of 3 runs over {n} consecutive pairs of the same {w}x{h} clip; {what}; "
-                  f"{len(cpus)} threads pinned one per physical core ({len(allowed)} logical CPUs allowed)",
+                  f"{len(cpus)} threads pinned one per physical core ({len(allowed)} logical CPUs visible, "
+                  f"cgroup CPU quota {quota if quota is not None else 'none'})",
     }))
 
 

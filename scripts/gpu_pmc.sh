@@ -1,5 +1,7 @@
 #!/bin/bash
-# HBM traffic of the dominant kernels from the PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE passes,
+# HBM traffic of the dominant kernels from the PMC counters: FETCH_SIZE and WRITE_SIZE in SEPARATE passes
+# (bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: calibrated on 4 B/lane and 16 B/lane streaming copies of known size,
+# profiles/round2/pmc/README.md),
 # kernel-trace only (MI355X_MICROARCH.md §HBM).  Short workload (34 frames, batches of 16): rocprofv3 --pmc was
 # unstable on longer runs on this pool.  Writes gpurun_out/pmc_traffic.json in the layout of profiles/pmc_traffic.json.
 mkdir -p gpurun_out
@@ -14,7 +16,7 @@ done; done
 cd $R
 ALGOS="$ALGOS" python - <<'PY'
 import csv,glob,collections,json,os
-dom={"tvl1":"void k_tvl1_step_fused<32, 4>","farn":"void k_farn_iteration_t<6>","brox":"void k_brox_sor_fused<64, 64, 5>"}
+dom={"tvl1":"void k_tvl1_step_fused<32, 4, true, 3>","farn":"void k_farn_iteration_t<6>","brox":"void k_brox_sor_fused<64, 64, 5>"}
 out={}
 for A in os.environ["ALGOS"].split():
     per={}

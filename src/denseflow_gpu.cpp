@@ -81,7 +81,15 @@ DenseFlow::DenseFlow(vector<path> video_paths, vector<path> output_dirs, string 
     device_bounding = this->save_type == "jpg" && !std::getenv("DF_HOST_BOUND");
     device_resize = !std::getenv("DF_HOST_RESIZE");
     const char *et = std::getenv("DF_ENCODE_THREADS");
-    const int hw = (int)std::thread::hardware_concurrency();
+    int hw = (int)std::thread::hardware_concurrency();
+    // a container CPU quota (cgroup v2 cpu.max) is the real core count: the MI355X boxes of this pool show 256
+    // logical CPUs and allow 16; 32 busy encoder threads there only get throttled
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        long long q = 0, per = 0;
+        if (fscanf(f, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0)
+            hw = std::max(1, std::min(hw, (int)(q / per)));
+        fclose(f);
+    }
     encode_threads = et ? std::max(1, std::atoi(et)) : std::max(1, std::min(hw > 0 ? hw : 1, 32));
     if (!check_param())
         throw std::runtime_error("check init param error.");
@@ -316,15 +324,48 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
 
 // ------------------------------------------------------------------------------------------------ the hot path
 
-// Results of the previous FlowBuffer whose last download is still in flight (dfx_submit_batch*): hand them to the
-// save stage now.
+// Submitted FlowBuffers are collected by their own thread: it waits for a buffer's tail (dfx_wait, the one entry point
+// that may run beside a submit) and hands the flows to the save stage the moment they are complete, in order.
+void DenseFlow::collect_flows() {
+    while (true) {
+        std::unique_ptr<PendingFlows> p;
+        {
+            unique_lock<mutex> lock(pending_mtx_);
+            pending_cv_.wait(lock, [&] { return !pending_q_.empty() || pending_closed_; });
+            if (pending_q_.empty())
+                return;
+            p = std::move(pending_q_.front());
+            pending_q_.pop();
+        }
+        if (p->ticket && p->handle && dfx_wait(p->handle, p->ticket) != DFX_OK)
+            pending_error_ = dfx_last_error(p->handle);
+        const bool fin = p->is_final;
+        flows_queue.push(std::move(p->flows), fin);
+        {
+            unique_lock<mutex> lock(pending_mtx_);
+            --pending_inflight_;
+            pending_cv_.notify_all();
+        }
+        if (fin)
+            return;
+    }
+}
+
+// Every submitted FlowBuffer has reached the save stage (needed before the engine handle is destroyed).
 void DenseFlow::flush_pending() {
-    if (!pending_)
-        return;
-    if (pending_->ticket && dfx_ && dfx_wait(dfx_, pending_->ticket) != DFX_OK)
-        throw std::runtime_error(dfx_last_error(dfx_));
-    flows_queue.push(std::move(pending_->flows), pending_->is_final);
-    pending_.reset();
+    unique_lock<mutex> lock(pending_mtx_);
+    pending_cv_.wait(lock, [&] { return pending_inflight_ == 0; });
+    if (!pending_error_.empty())
+        throw std::runtime_error(pending_error_);
+}
+
+void DenseFlow::enqueue_pending(std::unique_ptr<PendingFlows> p) {
+    unique_lock<mutex> lock(pending_mtx_);
+    // at most two FlowBuffers of flows wait for their tails: the one just submitted and the one before it
+    pending_cv_.wait(lock, [&] { return pending_inflight_ < 2; });
+    ++pending_inflight_;
+    pending_q_.push(std::move(p));
+    pending_cv_.notify_all();
 }
 
 // One FlowBuffer of gray frames -> M = max(N - |step|, 0) flows, on the GPU (reference :282-370).  The `stream`
@@ -403,26 +444,46 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
     }
     if (verbose)
         cout << "flows queue push a item" << endl;
-    flush_pending(); // the previous FlowBuffer's tail ran beside this one's uploads and compute
-    pending_.reset(new PendingFlows{FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start,
-                                               frames_gray.last_buffer, device_bounding && M > 0),
-                                    ticket, is_final});
-    // nothing queued behind this buffer (or the end of input): holding it back would gain nothing.
-    // DF_SYNC_FLOW=1 (A/B measurements): collect every FlowBuffer at once, like the synchronous dfx_calc_batch*.
+    // the collector thread waits for the tail (last download + hand-over) and pushes the flows to the save stage
+    // while this thread already submits the next FlowBuffer
+    enqueue_pending(std::unique_ptr<PendingFlows>(
+        new PendingFlows{FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start, frames_gray.last_buffer,
+                                    device_bounding && M > 0),
+                         ticket, is_final, ticket ? dfx_ : nullptr}));
+    // DF_SYNC_FLOW=1 (A/B measurements): collect every FlowBuffer at once, like the synchronous dfx_calc_batch*
     static const bool sync_flow = std::getenv("DF_SYNC_FLOW") != nullptr;
-    if (is_final || sync_flow || frames_gray_queue.size() == 0)
+    if (sync_flow)
         flush_pending();
 }
 
 void DenseFlow::calc_optflows(bool verbose) {
-    while (true) {
-        bool is_final = false;
-        FlowBuffer frames_gray = frames_gray_queue.pop(&is_final);
-        flows_final_ = is_final;
-        calc_optflows_imp(frames_gray, algorithm, step, false, stream);
-        if (is_final)
-            break;
+    {
+        unique_lock<mutex> lock(pending_mtx_);
+        pending_closed_ = false;
     }
+    thread collector([this] { collect_flows(); });
+    std::exception_ptr err;
+    try {
+        while (true) {
+            bool is_final = false;
+            FlowBuffer frames_gray = frames_gray_queue.pop(&is_final);
+            flows_final_ = is_final;
+            calc_optflows_imp(frames_gray, algorithm, step, false, stream);
+            if (is_final)
+                break;
+        }
+        flush_pending();
+    } catch (...) {
+        err = std::current_exception();
+    }
+    {
+        unique_lock<mutex> lock(pending_mtx_);
+        pending_closed_ = true;
+        pending_cv_.notify_all();
+    }
+    collector.join();
+    if (err)
+        std::rethrow_exception(err);
     if (verbose)
         cout << "calc optflows exit." << endl;
 }
@@ -588,7 +649,20 @@ vector<Mat> DenseFlowTestAccess::run_calc_optflows_imp(DenseFlow &d, const vecto
                                                         const string &algorithm, int step, bool bounded) {
     d.device_bounding = bounded;
     d.flows_final_ = true;
-    d.calc_optflows_imp(FlowBuffer(frames_gray, path(), 0, true), algorithm, step, false, d.stream);
+    thread collector([&d] { d.collect_flows(); });
+    std::exception_ptr err;
+    try {
+        d.calc_optflows_imp(FlowBuffer(frames_gray, path(), 0, true), algorithm, step, false, d.stream);
+        d.flush_pending();
+    } catch (...) {
+        err = std::current_exception();
+        unique_lock<mutex> lock(d.pending_mtx_);
+        d.pending_closed_ = true;
+        d.pending_cv_.notify_all();
+    }
+    collector.join();
+    if (err)
+        std::rethrow_exception(err);
     bool fin = false;
     return d.flows_queue.pop(&fin).item_data;
 }

@@ -512,9 +512,11 @@ def test_cli_level2_split_of_one_clip_over_device_pipelines(built, tmp_path, sou
         src = tmp_path / "clip"
         _write_pgm_dir(src, frames)
         extra = ["-if"]
+    lst = tmp_path / "list.txt"  # a list input records `.done/<stem>` (tools/denseflow.cpp:54-82)
+    lst.write_text(str(src) + "\n")
     outs = {}
     for tag, env in (("one", {}), ("split", {"DF_DEVICES": "0,0,0", "DF_BATCH_MAXSIZE": "5"})):
-        r = subprocess.run([built, str(src), "-o=" + str(tmp_path / tag), "-a=farn", f"-s={step}", "-b=20"] + extra,
+        r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / tag), "-a=farn", f"-s={step}", "-b=20"] + extra,
                            capture_output=True, text=True, env={**os.environ, **env})
         assert r.returncode == 0, r.stdout + r.stderr
         assert f"{n - abs(step)} farn flows) processed" in r.stdout, (tag, r.stdout)
