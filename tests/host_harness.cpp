@@ -184,3 +184,10 @@ long hh_parallel_sum(int n, int threads, int throws_at) {
     return sum.load();
 }
 }
+
+extern "C" {
+// DenseFlow::shard_range (the shell's Level-2 split) for the equivalence test with denseflow_amd/shard.py
+void hh_shard_range(int n_frames, int step, int rank, int world, int *begin, int *end) {
+    DenseFlow::shard_range(n_frames, step, rank, world, *begin, *end);
+}
+}

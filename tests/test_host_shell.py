@@ -524,3 +524,24 @@ def test_cli_level2_split_of_one_clip_over_device_pipelines(built, tmp_path, sou
                      for p in sorted((tmp_path / tag).rglob("*")) if p.is_file()}
     assert len(outs["one"]) == 2 * (n - abs(step)) + 1
     assert outs["one"] == outs["split"]
+
+
+def test_shell_and_bench_split_a_clip_the_same_way(harness):
+    """The host shell (DenseFlow::shard_range, -g with fewer videos than devices) and bench.py --split clip
+    (denseflow_amd/shard.py) must cut a clip into the same contiguous flow ranges: disjoint, covering every flow
+    once, each shard loading |step| overlap frames (reference padding logic src/denseflow_gpu.cpp:204-208)."""
+    from denseflow_amd.shard import shard_pairs
+
+    b, e = C.c_int(), C.c_int()
+    for n in (0, 1, 2, 5, 23, 300, 513):
+        for step in (1, -1, 2, -3, 7):
+            for world in (1, 2, 3, 8):
+                covered = []
+                for rank in range(world):
+                    harness.hh_shard_range(n, step, rank, world, C.byref(b), C.byref(e))
+                    sh = shard_pairs(n, step, world, rank)
+                    assert (b.value, e.value) == (sh.flow_begin, sh.flow_end), (n, step, world, rank)
+                    if sh.n_flows:
+                        assert sh.frame_begin == sh.flow_begin and sh.frame_end == sh.flow_end + abs(step)
+                    covered += list(range(b.value, e.value))
+                assert covered == list(range(max(n - abs(step), 0)))
