@@ -16,7 +16,7 @@ done; done
 cd $R
 ALGOS="$ALGOS" python - <<'PY'
 import csv,glob,collections,json,os
-dom={"tvl1":"void k_tvl1_step_fused<32, 4, true, 3>","farn":"void k_farn_iteration_t<6>","brox":"void k_brox_sor_fused<64, 64, 5>"}
+dom={"tvl1":"void k_tvl1_step_fused<32, 4, true, 3, true>","farn":"void k_farn_iteration_t<6>","brox":"void k_brox_sor_fused<64, 64, 5>"}
 out={}
 for A in os.environ["ALGOS"].split():
     per={}
