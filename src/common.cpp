@@ -150,11 +150,14 @@ static void convertFlowToPngImage(const Mat &flow_x, const Mat &flow_y, Mat &img
     for (int y = 0; y < flow_x.rows; ++y) {
         const float *fx = flow_x.ptr<float>(y), *fy = flow_y.ptr<float>(y);
         uchar *o = img_bgr.ptr<uchar>(y);
-        // rectangle(Point(0,0), Point(w-1, half_h)) is inclusive and rounds half_h; the second starts at half_h + 1
-        const uchar b = (y <= cv_round(half_h)) ? saturate_u8(bound_x / 4) : saturate_u8(bound_y / 4);
+        // rectangle(b, Point(0, 0), Point(w - 1, half_h), ...) (reference src/common.cpp:41): the double half_h
+        // becomes Point's int by TRUNCATION and the rectangle is inclusive; the second one starts at int(half_h + 1)
+        const uchar b = (y <= (int)half_h) ? saturate_u8(bound_x / 4) : saturate_u8(bound_y / 4);
         for (int x = 0; x < flow_x.cols; ++x) {
-            o[3 * x] = saturate_u8((double)fx[x] * eps_x_inv + 128.);
-            o[3 * x + 1] = saturate_u8((double)fy[x] * eps_y_inv + 128.);
+            // Mat::convertTo(CV_8U, alpha, beta) on a float source works in float: saturate_cast<uchar>(v*a + b)
+            const float vx = fx[x] * eps_x_inv + 128.f, vy = fy[x] * eps_y_inv + 128.f;
+            o[3 * x] = saturate_u8((double)vx);
+            o[3 * x + 1] = saturate_u8((double)vy);
             o[3 * x + 2] = b;
         }
     }

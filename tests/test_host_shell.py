@@ -545,3 +545,33 @@ def test_shell_and_bench_split_a_clip_the_same_way(harness):
                         assert sh.frame_begin == sh.flow_begin and sh.frame_end == sh.flow_end + abs(step)
                     covered += list(range(b.value, e.value))
                 assert covered == list(range(max(n - abs(step), 0)))
+
+
+@pytest.mark.parametrize("h", [7, 8, 9, 11, 191])
+def test_png_bound_channel_split_and_float_scaling_follow_the_reference(harness, h):
+    """convertFlowToPngImage (reference src/common.cpp:18-46): rows 0 .. int(h/2) carry bound_x/4, the rest bound_y/4
+    (Point(w-1, half_h) truncates the double; ADVICE r1 found 5 rows instead of 4 at h = 7), and the two flow channels
+    are Mat::convertTo(CV_8U, 1/(bound/128), 128) evaluated in FLOAT."""
+    from PIL import Image
+
+    rng = np.random.default_rng(h)
+    w = 12
+    fx = rng.uniform(-9, 9, (h, w)).astype(np.float32)
+    fy = rng.uniform(-2, 2, (h, w)).astype(np.float32)
+    buf = np.zeros(1 << 16, np.uint8)
+    n = harness.hh_encode_flow_png(fx.ctypes.data_as(C.c_void_p), fy.ctypes.data_as(C.c_void_p), w, h,
+                                   buf.ctypes.data_as(C.c_void_p), buf.size)
+    png = np.array(Image.open(io.BytesIO(buf[:n].tobytes())))  # RGB order: R = third channel (bound), G = y, B = x
+
+    def bound(f, lim):
+        b = min(255.0 * 4, np.ceil((min(lim, float(np.abs(f).max())) * 128.0 / 127.0) / 4) * 4)
+        return b + 4 if int(b) % 8 == 0 else b
+
+    bx, by = bound(fx, w), bound(fy, h)
+    rows_x = int(h / 2) + 1  # inclusive rectangle up to the truncated half height
+    assert np.all(png[:rows_x, :, 0] == int(np.rint(bx / 4))) and np.all(png[rows_x:, :, 0] == int(np.rint(by / 4)))
+    for f, b, ch in ((fx, bx, 2), (fy, by, 1)):
+        inv = np.float32(1.0 / ((1.0 / 128.0) * b))
+        v = f * inv + np.float32(128.0)  # float32 arithmetic, as cv::Mat::convertTo
+        assert v.dtype == np.float32
+        assert np.array_equal(png[..., ch], np.clip(np.rint(v.astype(np.float64)), 0, 255).astype(np.uint8))
