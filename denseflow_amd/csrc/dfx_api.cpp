@@ -241,10 +241,12 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     // per batch and direction.
     const size_t in_fb = c->in_row_bytes() * c->in_h();
     const size_t out_pb = out.quantized ? 2 * plane : plane * 8; // bytes per pair leaving the device
-    bool bounce = host_mode && in_fb <= (256u << 10) && (size_t)(B + astep) * in_fb <= (256u << 20) &&
-                  (size_t)B * out_pb <= (256u << 20);
-    if (bounce) {
-        rc = ensure_bounce(c, (size_t)(B + astep) * in_fb, (size_t)B * out_pb);
+    // Decided per direction: a 224x224 frame is 50 KB (gathered), but its float flow is 401 KB — one direct copy per
+    // flow (~10 us of driver time) is cheaper than a second pass of host memcpy over 120 MB per clip.
+    const bool bounce_in = host_mode && in_fb <= (256u << 10) && (size_t)(B + astep) * in_fb <= (256u << 20);
+    const bool bounce = bounce_in && out_pb <= (256u << 10) && (size_t)B * out_pb <= (256u << 20); // results
+    if (bounce_in) {
+        rc = ensure_bounce(c, (size_t)(B + astep) * in_fb, bounce ? (size_t)B * out_pb : 0);
         if (rc != DFX_OK)
             return rc;
     } else if (host_mode && M <= B && M >= 32) {
@@ -284,7 +286,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         // the staging set was last read by the frame preparation of batch q-2 (compute stream)
         if (seq0 + k >= 2)
             HIPCHK(c, hipStreamWaitEvent(c->copy_stream, c->ev_compute[par(k)], 0));
-        if (bounce) {
+        if (bounce_in) {
             if (seq0 + k >= 2) // the copy that last read this bounce buffer (batch q-2) has long finished; make it formal
                 HIPCHK(c, hipEventSynchronize(c->ev_h2d[par(k)]));
             unsigned char *hb = c->h_in[par(k)];
