@@ -66,6 +66,7 @@ struct Tvl1LevelCtx {
     unsigned int *level_done_count; // device counter of pairs that finished the level
     volatile int *host_done_flag;   // pinned host word: set to done_token when every pair finished
     int done_token;
+    int split_warp; // the backward warp runs as its own kernel in front of every step: the step kernel skips phase WARP
 };
 
 static inline int dfx_round_up(int v, int m) { return (v + m - 1) / m * m; }

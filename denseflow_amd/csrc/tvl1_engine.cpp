@@ -69,6 +69,7 @@ class Tvl1Engine final : public AlgoEngine {
     hipEvent_t ev_lvl[DFX_LVL_MAX][2] = {};
     int done_token = 0;
     int group_override = 0;
+    bool split_warp = false; // backward warp as its own kernel in front of every step (packed step kernels only)
     int launched_steps[DFX_LVL_MAX] = {0};
 
     Tvl1LoopCfg loop{};
@@ -112,6 +113,10 @@ int Tvl1Engine::create() {
         return dfx_fail(c, DFX_ERR_INVALID, "invalid TVL1 parameters");
     if (const char *g = std::getenv("DFX_GROUP"))
         group_override = std::atoi(g);
+    // the dedicated warp kernel does not write the grad plane: only the packed tile functions (impl 0 / 3) rebuild it
+    split_warp = (p.impl == 0 || p.impl == 3) && p.tvl1_iterations > 0; // zero iterations: warps inside the step kernel
+    if (const char *g = std::getenv("DFX_TVL1_SPLIT_WARP")) // A/B switch for measurements
+        split_warp = split_warp && std::atoi(g) != 0;
 
     // pyramid (A.2 step 3): cvRound(size*scaleStep) per level; a level below 16 px is discarded
     {
@@ -254,6 +259,7 @@ Tvl1LevelCtx Tvl1Engine::level_ctx(int s, int n_pairs) const {
     x.level_done_count = d_level_done;
     x.host_done_flag = d_done_flag;
     x.done_token = 0;
+    x.split_warp = split_warp ? 1 : 0;
     return x;
 }
 
@@ -286,9 +292,12 @@ int Tvl1Engine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
             int step_id = 0;
             HIPCHK(c, hipEventRecord(ev_lvl[s][0], c->stream));
             for (int g = 0;; ++g) {
-                for (int i = 0; i < G; ++i)
+                for (int i = 0; i < G; ++i) {
+                    if (split_warp)
+                        tvl1_launch_warp(c->stream, x, step_id);
                     tvl1_launch_step(c->stream, x, step_id++, impl, tile_h);
-                c->stats.kernel_launches += G;
+                }
+                c->stats.kernel_launches += (uint64_t)G * (split_warp ? 2 : 1);
                 HIPCHK(c, hipEventRecord(ev_group[g & 1], c->stream));
                 if (g >= 1) { // look at the group before the one just enqueued: the device never idles
                     HIPCHK(c, hipEventSynchronize(ev_group[(g - 1) & 1]));

@@ -15,6 +15,7 @@ void tvl1_launch_centered_gradient(hipStream_t s, const float *frame_I, float *f
                                    long long frame_stride, const int *frame_slots, int n_frames, long long off, int w,
                                    int h, int pitch);
 void tvl1_launch_level_begin(hipStream_t s, const Tvl1LevelCtx &c, int first_level);
+void tvl1_launch_warp(hipStream_t s, const Tvl1LevelCtx &c, int step_id); // dedicated backward-warp kernel of a step
 void tvl1_launch_step(hipStream_t s, const Tvl1LevelCtx &c, int step_id, int impl, int tile_h);
 int tvl1_step_blocks(const Tvl1LevelCtx &c, int impl, int tile_h); // workgroups per pair of a step launch
 int tvl1_fused_max_k(int tile_h);                           // largest supported inner-iteration fusion

@@ -27,6 +27,8 @@ for cfg in configs:
     impl, k, b = parts[:3]
     th = parts[3] if len(parts) > 3 else 0
     extra = {"tvl1_nscales": int(os.environ["NSCALES"])} if os.environ.get("NSCALES") else {}
+    if os.environ.get("ITERS"):
+        extra["tvl1_iterations"] = int(os.environ["ITERS"])
     if os.environ.get("EPS"):
         extra["tvl1_epsilon"] = float(os.environ["EPS"])
     eng = denseflow_amd.FlowEngine(W, H, ALGO, impl=impl, tvl1_fuse_k=k, max_batch=b, tvl1_tile_h=th, **extra)

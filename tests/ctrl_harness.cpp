@@ -8,9 +8,23 @@
 #include "../denseflow_amd/csrc/tvl1_ctrl.h"
 #include "../oracle/tvl1_oracle.h"
 
+// split_warp = 0: a warp occupies a step of its own (the warp phase inside the step kernel);
+// split_warp = 1: the dedicated warp kernel runs in front of the step kernel of the SAME step id (k_tvl1_warp): the warp
+//                 starts the loop at this very step, and with zero iterations the step kernel skips the pair.
+extern "C" int ctrl_replay_level_ex(const float *I0, const float *I1, float *u1, float *u2, int W, int H, int warps,
+                                    int iterations, int fuse_k, double eps, double lambda, double theta, double tau,
+                                    int *iters_out, int *n_checks_out, int *steps_out, int split_warp);
+
 extern "C" int ctrl_replay_level(const float *I0, const float *I1, float *u1, float *u2, int W, int H, int warps,
                                  int iterations, int fuse_k, double eps, double lambda, double theta, double tau,
                                  int *iters_out, int *n_checks_out, int *steps_out) {
+    return ctrl_replay_level_ex(I0, I1, u1, u2, W, H, warps, iterations, fuse_k, eps, lambda, theta, tau, iters_out,
+                                n_checks_out, steps_out, 0);
+}
+
+extern "C" int ctrl_replay_level_ex(const float *I0, const float *I1, float *u1, float *u2, int W, int H, int warps,
+                                    int iterations, int fuse_k, double eps, double lambda, double theta, double tau,
+                                    int *iters_out, int *n_checks_out, int *steps_out, int split_warp) {
     const size_t n = (size_t)W * H;
     std::vector<float> buf(n * 11, 0.f);
     float *I1x = buf.data(), *I1y = I1x + n, *I1w = I1y + n, *I1wx = I1w + n, *I1wy = I1wx + n, *grad = I1wy + n,
@@ -30,8 +44,9 @@ extern "C" int ctrl_replay_level(const float *I0, const float *I1, float *u1, fl
     for (; st.phase != TVL1_PH_LEVEL_DONE && step_id < limit; ++step_id) {
         if (st.phase == TVL1_PH_WARP) {
             orc_tvl1_warp_backward(I0, I1, I1x, I1y, u1, u2, W, H, I1w, I1wx, I1wy, grad, rho);
-            tvl1_begin_loop(st, cfg, step_id);
-            continue;
+            tvl1_begin_loop(st, cfg, split_warp ? step_id - 1 : step_id);
+            if (!split_warp || st.phase != TVL1_PH_ITER)
+                continue; // split: the step kernel of this step id follows; it skips pairs that are not iterating
         }
         const Tvl1StepPlan p = tvl1_plan_step(st, cfg, step_id);
         if (p.n_iters <= 0)
