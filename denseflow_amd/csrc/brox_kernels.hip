@@ -8,6 +8,7 @@
 // the oracle's operation order and the file is compiled with -ffp-contract=off, so results are bit-identical
 // to the oracle.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "brox_kernels.h"
 
@@ -267,7 +268,13 @@ __global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, in
 // back.  Same per-pixel expression, same order: bit-identical to the one-launch-per-half-sweep form.
 #define BROX_PR 2 // patch rows per thread
 // Tile BROX_TW x BROX_TH (one thread per 2x2 patch), up to BROX_S sweeps per launch (halo 2*BROX_S).
-template <int BROX_TW, int BROX_TH, int BROX_S>
+// MODE 0: two barriers per half sweep (update | barrier | publish w | barrier) — the first form, kept for A/B.
+// MODE 1: one.  A half sweep of colour c reads w only at pixels of colour 1-c (the four neighbours; at a clamped tile
+//         edge the pixel's own entry) and writes w only at pixels of colour c, each by the one thread that owns it, so
+//         publishing right after the update races with nothing; only the next half sweep has to wait.
+// MODE 2: as 1, and a wavefront (= a band of 4 tile rows) whose rows can no longer influence the owned region skips
+//         its update: after sweep s of n the result is needed on the owned rows +- (2(n-1-s)+1), the halo is 2*BROX_S.
+template <int BROX_TW, int BROX_TH, int BROX_S, int MODE = 0>
 __global__ __launch_bounds__(BROX_TW *BROX_TH / 4) void k_brox_sor_fused(BroxLevelCtx c, int uv_set, int d_src,
                                                                          int n_sweeps, int tiles_x) {
     constexpr int BROX_HALO = 2 * BROX_S;
@@ -318,6 +325,41 @@ __global__ __launch_bounds__(BROX_TW *BROX_TH / 4) void k_brox_sor_fused(BroxLev
     }
     __syncthreads();
     const float omega = c.omega;
+    if (MODE >= 1) {
+        constexpr int ROWS_PER_WAVE = BROX_PR * (64 / (BROX_TW / 2)); // BROX_TW / 2 patch columns per patch row
+        const int band0 = (ly0 / ROWS_PER_WAVE) * ROWS_PER_WAVE;     // first tile row of this wavefront
+        for (int sw = 0; sw < n_sweeps; ++sw) {
+            const int m = 2 * (n_sweeps - 1 - sw) + 1;
+            const bool live = MODE < 2 || (band0 + ROWS_PER_WAVE - 1 >= BROX_HALO - m && band0 < BROX_TH - BROX_HALO + m);
+#pragma unroll
+            for (int color = 0; color < 2; ++color) {
+                if (live) {
+#pragma unroll
+                    for (int i = 0; i < BROX_PR; ++i) {
+                        const int k = (i + color) & 1;
+                        const int lx = lx0 + k, ly = ly0 + i;
+                        const int lxl = max(lx - 1, 0), lxr = min(lx + 1, BROX_TW - 1);
+                        const int lyd = max(ly - 1, 0), lyu = min(ly + 1, BROX_TH - 1);
+                        const float su = (((gl[i][k] * WU[ly][lxl] + gr[i][k] * WU[ly][lxr]) + gd[i][k] * WU[lyd][lx]) +
+                                          gu[i][k] * WU[lyu][lx]) -
+                                         gs[i][k] * uu[i][k];
+                        const float sv = (((gl[i][k] * WV[ly][lxl] + gr[i][k] * WV[ly][lxr]) + gd[i][k] * WV[lyd][lx]) +
+                                          gu[i][k] * WV[lyu][lx]) -
+                                         gs[i][k] * vv[i][k];
+                        const float du_n =
+                            (1.0f - omega) * du[i][k] + omega * (idu[i][k] * ((su - nu[i][k]) - nd[i][k] * dv[i][k]));
+                        const float dv_n =
+                            (1.0f - omega) * dv[i][k] + omega * (idv[i][k] * ((sv - nv[i][k]) - nd[i][k] * du_n));
+                        du[i][k] = du_n;
+                        dv[i][k] = dv_n;
+                        WU[ly][lx] = uu[i][k] + du_n;
+                        WV[ly][lx] = vv[i][k] + dv_n;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else
     for (int sw = 0; sw < n_sweeps; ++sw) {
 #pragma unroll
         for (int color = 0; color < 2; ++color) {
@@ -462,15 +504,22 @@ static void sor_cfg(int cfg, int &tw, int &th, int &S) {
     else if (cfg == 642 || cfg == 643)
         S = cfg - 640;
 }
-template <int TW, int TH, int S>
+#ifndef BROX_SOR_MODE_DEFAULT
+#define BROX_SOR_MODE_DEFAULT 0
+#endif
+template <int TW, int TH, int S, int MODE = 0>
 static void sor_launch(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps) {
     const int tiles_x = (c.w + (TW - 4 * S) - 1) / (TW - 4 * S), tiles_y = (c.h + (TH - 4 * S) - 1) / (TH - 4 * S);
-    hipLaunchKernelGGL((k_brox_sor_fused<TW, TH, S>), dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(TW * TH / 4), 0, s, c,
-                       uv_set, d_src, n_sweeps, tiles_x);
+    hipLaunchKernelGGL((k_brox_sor_fused<TW, TH, S, MODE>), dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(TW * TH / 4), 0,
+                       s, c, uv_set, d_src, n_sweeps, tiles_x);
 }
 void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int cfg) {
     int tw, th, S;
     sor_cfg(cfg, tw, th, S);
+    // barrier scheme of the default tile (k_brox_sor_fused MODE); DFX_BROX_SOR is the A/B switch of the measurements
+    // and parity tests, looked up per launch so that one process can compare the modes
+    const char *e = getenv("DFX_BROX_SOR");
+    const int mode = e ? atoi(e) : BROX_SOR_MODE_DEFAULT;
     if (tw == 128)
         sor_launch<128, 32, 2>(s, c, uv_set, d_src, n_sweeps);
     else if (th == 32)
@@ -479,6 +528,10 @@ void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int
         sor_launch<64, 64, 2>(s, c, uv_set, d_src, n_sweeps);
     else if (S == 3)
         sor_launch<64, 64, 3>(s, c, uv_set, d_src, n_sweeps);
+    else if (mode == 1)
+        sor_launch<64, 64, 5, 1>(s, c, uv_set, d_src, n_sweeps);
+    else if (mode == 2)
+        sor_launch<64, 64, 5, 2>(s, c, uv_set, d_src, n_sweeps);
     else
         sor_launch<64, 64, 5>(s, c, uv_set, d_src, n_sweeps);
 }

@@ -17,6 +17,12 @@
 #include "dfx_internal.h"
 #include "tvl1_kernels.h"
 
+// Tile geometry of the default step kernel (k_tvl1_step_fused, Tvl1LevelCtx::geom): bit 0 = tile columns start at
+// x = 0, bit 1 = halo as wide as the step is long.
+#ifndef DFX_TVL1_GEOM_DEFAULT
+#define DFX_TVL1_GEOM_DEFAULT 0
+#endif
+
 namespace {
 
 struct Level {
@@ -70,6 +76,7 @@ class Tvl1Engine final : public AlgoEngine {
     int done_token = 0;
     int group_override = 0;
     bool split_warp = false; // backward warp as its own kernel in front of every step (packed step kernels only)
+    int geom = 0;            // step-kernel tile geometry (Tvl1LevelCtx::geom), default tile function only
     int launched_steps[DFX_LVL_MAX] = {0};
 
     Tvl1LoopCfg loop{};
@@ -117,6 +124,10 @@ int Tvl1Engine::create() {
     split_warp = (p.impl == 0 || p.impl == 3) && p.tvl1_iterations > 0; // zero iterations: warps inside the step kernel
     if (const char *g = std::getenv("DFX_TVL1_SPLIT_WARP")) // A/B switch for measurements
         split_warp = split_warp && std::atoi(g) != 0;
+
+    geom = (p.impl == 0 && (p.tvl1_tile_h == 0 || p.tvl1_tile_h == 321)) ? DFX_TVL1_GEOM_DEFAULT : 0;
+    if (const char *g = std::getenv("DFX_TVL1_GEOM")) // A/B switch for measurements and the parity tests
+        geom = (p.impl == 0 && (p.tvl1_tile_h == 0 || p.tvl1_tile_h == 321)) ? (std::atoi(g) & 3) : 0;
 
     // pyramid (A.2 step 3): cvRound(size*scaleStep) per level; a level below 16 px is discarded
     {
@@ -260,6 +271,7 @@ Tvl1LevelCtx Tvl1Engine::level_ctx(int s, int n_pairs) const {
     x.host_done_flag = d_done_flag;
     x.done_token = 0;
     x.split_warp = split_warp ? 1 : 0;
+    x.geom = geom;
     return x;
 }
 

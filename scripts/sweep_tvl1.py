@@ -26,6 +26,10 @@ for cfg in configs:
     parts = [int(v) for v in cfg.split(":")]
     impl, k, b = parts[:3]
     th = parts[3] if len(parts) > 3 else 0
+    if len(parts) > 4:  # step-kernel tile geometry (tvl1) — read by dfx_create
+        os.environ["DFX_TVL1_GEOM"] = str(parts[4])
+    if len(parts) > 5:  # fused-SOR barrier scheme (brox) — read per launch
+        os.environ["DFX_BROX_SOR"] = str(parts[5])
     extra = {"tvl1_nscales": int(os.environ["NSCALES"])} if os.environ.get("NSCALES") else {}
     if os.environ.get("ITERS"):
         extra["tvl1_iterations"] = int(os.environ["ITERS"])
@@ -45,7 +49,7 @@ for cfg in configs:
     same = "ref" if ref is None else ("bit-identical" if torch.equal(out, ref) else "DIFFERENT max|d|=%g" % float((out - ref).abs().max()))
     if ref is None:
         ref = out
-    print(f"impl={impl} K={k} B={b} TH={th}: {reps*(NF-1)/dt:8.1f} pairs/s  dev_ms/pair={st.device_ms/st.pairs:7.3f} step_ms/pair={st.step_ms/st.pairs:7.3f} "
+    print(f"impl={impl} K={k} B={b} TH={th} cfg={cfg}: {reps*(NF-1)/dt:8.1f} pairs/s  dev_ms/pair={st.device_ms/st.pairs:7.3f} step_ms/pair={st.step_ms/st.pairs:7.3f} "
           f"launches/pair={st.kernel_launches/st.pairs:7.1f} noop={st.noop_steps/max(st.step_launches,1):.3f} "
           f"alg_GB/s(step)={st.step_algorithmic_bytes/(st.step_ms*1e-3)/1e9:8.1f}  [{same}]", flush=True)
     if os.environ.get("SWEEP_LEVELS"):

@@ -78,15 +78,18 @@ def test_large_pyramid_1080p(dfx, oracle):
     assert np.abs(out - gt)[64:-64, 64:-64].mean() < 0.05
 
 
-def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
+@pytest.mark.parametrize("sor_mode", [0, 1, 2])
+def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle, sor_mode, monkeypatch):
     """The fused SOR kernel (LDS tile, recomputed halo, several sweeps per launch) must not change a bit
-    relative to the simple form, for even and odd solver-iteration counts."""
+    relative to the simple form, for even and odd solver-iteration counts — with two barriers per half sweep (mode 0),
+    with one (mode 1), and with the wavefronts of dead halo rows skipping their updates (mode 2)."""
+    monkeypatch.setenv("DFX_BROX_SOR", str(sor_mode))
     # large enough that workgroups of one launch are NOT all co-resident: an in-place update of du/dv would
     # race with neighbours reading their halo (this caught exactly that bug; the kernel ping-pongs two sets)
     w, h = 1000, 600
     clip = SynthClip(w, h, 8)
     f0, f1 = clip.frame(0), clip.frame(1)
-    for solver in (10, 3):
+    for solver in (10, 3, 7):
         with dfx.FlowEngine(w, h, "brox", impl=1, brox_solver_iterations=solver) as eng:
             simple = eng.calc(f0, f1)
         with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver) as eng:
