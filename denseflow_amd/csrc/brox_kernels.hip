@@ -505,7 +505,7 @@ static void sor_cfg(int cfg, int &tw, int &th, int &S) {
         S = cfg - 640;
 }
 #ifndef BROX_SOR_MODE_DEFAULT
-#define BROX_SOR_MODE_DEFAULT 0
+#define BROX_SOR_MODE_DEFAULT 2
 #endif
 template <int TW, int TH, int S, int MODE = 0>
 static void sor_launch(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps) {

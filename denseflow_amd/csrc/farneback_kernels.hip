@@ -15,6 +15,8 @@
 // Compiled with -ffp-contract=off: every a*b+c is a rounded multiply then a rounded add, like the oracle.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "farneback_kernels.h"
 
 #define FARN_HALF_MAX 8 // box half-width supported by the fused iteration kernel (winSize <= 17)
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(256) void k_farn_u8_to_f32(const unsigned char *src
 __global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ frames, long long frame_stride, int W,
                                                      int H, int pitch0, int dst_h, float ify,
                                                      const float *__restrict__ ker, int half,
-                                                     float *__restrict__ tmpv, long long tmpv_frame_stride) {
+                                                     float *__restrict__ tmpv, long long tmpv_frame_stride,
+                                                     int skip_zero_weights) {
     // one thread = one column of one destination row: BOTH source rows the bilinear resize samples (y1, y1 + 1).
     // Their tap windows overlap in all but one row each, so the interior path loads 2 values per tap pair for the
     // two outputs (a rolling pair of registers supplies the other two) instead of 4.
@@ -65,6 +68,28 @@ __global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ f
     const int yr0 = min(y1, H - 1), yr1 = min(y1 + 1, H - 1);
     const float *src = frames + (long long)blockIdx.z * frame_stride;
     float *out = tmpv + (long long)blockIdx.z * tmpv_frame_stride + (long long)(2 * dy) * pitch0 + x;
+    // The resize weighs source row y1 + 1 with (sy - y1): exactly 0 whenever the level's scale divides the frame
+    // (every level of a 2^k pyramid but the odd-sized ones).  k_farn_blur_h_resize then never reads that row, so it
+    // is not computed either (skip_zero_weights: A/B switch, same bits both ways).
+    if (skip_zero_weights && sy - (float)y1 == 0.0f) {
+        float v;
+        if (yr0 - half >= 0 && yr0 + half <= H - 1) {
+            const float *c0 = src + (long long)yr0 * pitch0 + x;
+            v = c0[0] * ker[0];
+#pragma unroll 8
+            for (int j = 1; j <= half; ++j)
+                v = v + (c0[-(long long)j * pitch0] + c0[(long long)j * pitch0]) * ker[j];
+        } else {
+            v = src[(long long)yr0 * pitch0 + x] * ker[0];
+            for (int j = 1; j <= half; ++j) {
+                const float a = src[(long long)reflect101_low(yr0 - j, H - 1) * pitch0 + x];
+                const float b = src[(long long)reflect101_high(yr0 + j, H - 1) * pitch0 + x];
+                v = v + (a + b) * ker[j];
+            }
+        }
+        out[0] = v;
+        return;
+    }
     if (yr1 == yr0 + 1 && yr0 - half >= 0 && yr1 + half <= H - 1) {
         const float *c0 = src + (long long)yr0 * pitch0 + x, *c1 = c0 + pitch0;
         float lo_prev = c0[0], hi_prev = c1[0]; // row yr0 - (j-1) seen from output 1, row yr1 + (j-1) from output 0
@@ -101,7 +126,8 @@ __global__ __launch_bounds__(256) void k_farn_blur_h_resize(const float *__restr
                                                             long long tmpv_frame_stride, int W, int H, int pitch0,
                                                             int dst_w, int dst_h, int dst_pitch, float ifx, float ify,
                                                             const float *__restrict__ ker, int half,
-                                                            float *__restrict__ pyr, long long pyr_frame_stride) {
+                                                            float *__restrict__ pyr, long long pyr_frame_stride,
+                                                            int skip_zero_weights) {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (dx >= dst_w || dy >= dst_h)
@@ -111,12 +137,21 @@ __global__ __launch_bounds__(256) void k_farn_blur_h_resize(const float *__restr
     const int x2 = x1 + 1, y2 = y1 + 1;
     const int xc[2] = {min(x1, W - 1), min(x2, W - 1)};
     const float *rows = tmpv + (long long)blockIdx.z * tmpv_frame_stride + (long long)(2 * dy) * pitch0;
+    // A bilinear tap with weight exactly 0 adds +0 to a finite, non-negative sum (blurred 8-bit frames): it is not
+    // evaluated.  With a 2^k pyramid that is 3 of the 4 taps at every level whose size divides the frame's —
+    // the resize degenerates to point sampling of the blurred frame, and level 0 to the blur itself.
+    const bool use_k1 = !skip_zero_weights || (sx - (float)x1) != 0.0f;
+    const bool use_r1 = !skip_zero_weights || (sy - (float)y1) != 0.0f;
     float bl[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const float *row = rows + (long long)r * pitch0;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
+            if ((r == 1 && !use_r1) || (k == 1 && !use_k1)) {
+                bl[r][k] = 0.0f;
+                continue;
+            }
             const int cx = xc[k];
             float res = row[cx] * ker[0];
             if (cx - half >= 0 && cx + half <= W - 1) { // window inside the row: plain indices
@@ -188,6 +223,77 @@ __global__ __launch_bounds__(256) void k_farn_polyexp(const float *pyr, long lon
         R[2 * ps] = b1 * pc.ig03 + b5 * pc.ig33;
         R[3 * ps] = b1 * pc.ig03 + b4 * pc.ig33;
         R[4 * ps] = b6 * pc.ig55;
+    }
+}
+
+// B.5 again, ROWS image rows per workgroup: a thread walks down its column with the 11 source values of the vertical
+// pass in registers (one new load per row instead of eleven), the three vertical sums of a row go to one of two LDS row
+// buffers (one barrier per row) and the horizontal combinations are the ones of k_farn_polyexp, in the same order.
+template <int ROWS>
+__global__ __launch_bounds__(256) void k_farn_polyexp_rows(const float *__restrict__ pyr, long long pyr_frame_stride,
+                                                           const int *__restrict__ frame_slots,
+                                                           float *__restrict__ frame_R, long long frame_stride,
+                                                           FarnLevelGeom L, FarnPolyConsts pc) {
+    constexpr int N = 5;
+    __shared__ float row[2][3][256];
+    const int tx = threadIdx.x;
+    const int y0 = blockIdx.y * ROWS;
+    const int x = blockIdx.x * (256 - 2 * N) + tx - N;
+    const float *src = pyr + (long long)blockIdx.z * pyr_frame_stride;
+    const int xw = min(max(x, 0), L.w - 1);
+    const bool writes = tx >= N && tx + N < 256 && x < L.w;
+    const long long ps = (long long)L.pitch * L.h;
+    float *Rbase = frame_R + (long long)frame_slots[blockIdx.z] * frame_stride + L.r_off + x;
+    float win[2 * N + 1]; // win[k] = source row clamp(y - N + k)
+#pragma unroll
+    for (int k = 0; k <= 2 * N; ++k)
+        win[k] = src[(long long)min(max(y0 - N + k, 0), L.h - 1) * L.pitch + xw];
+#pragma unroll 2
+    for (int r = 0; r < ROWS; ++r) {
+        const int y = y0 + r;
+        if (y >= L.h)
+            break; // the whole workgroup
+        const float nxt = src[(long long)min(y + N + 1, L.h - 1) * L.pitch + xw]; // enters the window at row y + 1
+        float a0 = win[N] * pc.g[0];
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int k = 1; k <= N; ++k) {
+            const float t0 = win[N - k];
+            const float t1 = win[N + k];
+            a0 = a0 + pc.g[k] * (t0 + t1);
+            a1 = a1 + pc.xg[k] * (t1 - t0);
+            a2 = a2 + pc.xxg[k] * (t0 + t1);
+        }
+        float(*rb)[256] = row[r & 1];
+        rb[0][tx] = a0;
+        rb[1][tx] = a1;
+        rb[2][tx] = a2;
+        __syncthreads(); // buffer r & 1 is rewritten at row r + 2, after every thread has passed the barrier of row r + 1
+        if (writes) {
+            float b1 = pc.g[0] * rb[0][tx];
+            float b3 = pc.g[0] * rb[1][tx];
+            float b5 = pc.g[0] * rb[2][tx];
+            float b2 = 0, b4 = 0, b6 = 0;
+#pragma unroll
+            for (int k = 1; k <= N; ++k) {
+                b1 = b1 + (rb[0][tx + k] + rb[0][tx - k]) * pc.g[k];
+                b4 = b4 + (rb[0][tx + k] + rb[0][tx - k]) * pc.xxg[k];
+                b2 = b2 + (rb[0][tx + k] - rb[0][tx - k]) * pc.xg[k];
+                b3 = b3 + (rb[1][tx + k] + rb[1][tx - k]) * pc.g[k];
+                b6 = b6 + (rb[1][tx + k] - rb[1][tx - k]) * pc.xg[k];
+                b5 = b5 + (rb[2][tx + k] + rb[2][tx - k]) * pc.g[k];
+            }
+            float *R = Rbase + (long long)y * L.pitch;
+            R[0] = b3 * pc.ig11;
+            R[ps] = b2 * pc.ig11;
+            R[2 * ps] = b1 * pc.ig03 + b5 * pc.ig33;
+            R[3 * ps] = b1 * pc.ig03 + b4 * pc.ig33;
+            R[4 * ps] = b6 * pc.ig55;
+        }
+#pragma unroll
+        for (int k = 0; k < 2 * N; ++k)
+            win[k] = win[k + 1];
+        win[2 * N] = nxt;
     }
 }
 
@@ -540,11 +646,24 @@ void farn_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long sr
                        dst, dst_frame_stride, w, h, pitch);
 }
 
+// Zero-weight taps of the pyramid resize are not evaluated (k_farn_blur_v / k_farn_blur_h_resize); DFX_FARN_SKIP0 is
+// the A/B switch of the measurements and the parity test, looked up per launch.
+#ifndef FARN_POLYROWS_DEFAULT
+#define FARN_POLYROWS_DEFAULT 16
+#endif
+#ifndef FARN_SKIP0_DEFAULT
+#define FARN_SKIP0_DEFAULT 1
+#endif
+static int farn_skip_zero_weights() {
+    const char *e = getenv("DFX_FARN_SKIP0");
+    return e ? atoi(e) : FARN_SKIP0_DEFAULT;
+}
+
 void farn_launch_blur_v(hipStream_t s, const float *frames, long long frame_stride, int n_frames, int W, int H,
                         int pitch0, int dst_h, float ify, const float *ker_half, int half, float *tmpv,
                         long long tmpv_frame_stride) {
     hipLaunchKernelGGL(k_farn_blur_v, grid64x4(W, dst_h, n_frames), dim3(256), 0, s, frames, frame_stride, W, H,
-                       pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride);
+                       pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride, farn_skip_zero_weights());
 }
 
 void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_frame_stride, int n_frames, int W,
@@ -552,12 +671,21 @@ void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_
                                const float *ker_half, int half, float *pyr, long long pyr_frame_stride) {
     hipLaunchKernelGGL(k_farn_blur_h_resize, grid64x4(dst_w, dst_h, n_frames), dim3(256), 0, s, tmpv,
                        tmpv_frame_stride, W, H, pitch0, dst_w, dst_h, dst_pitch, ifx, ify, ker_half, half, pyr,
-                       pyr_frame_stride);
+                       pyr_frame_stride, farn_skip_zero_weights());
 }
 
 void farn_launch_polyexp(hipStream_t s, const float *pyr, long long pyr_frame_stride, int n_frames,
                          const int *frame_slots, float *frame_R, long long frame_stride, FarnLevelGeom L,
                          FarnPolyConsts pc) {
+    // DFX_FARN_POLYROWS (A/B switch, looked up per launch): 0 = one image row per workgroup, 16 = k_farn_polyexp_rows<16>
+    const char *e = getenv("DFX_FARN_POLYROWS");
+    const int rows = e ? atoi(e) : FARN_POLYROWS_DEFAULT;
+    if (rows == 16) {
+        const dim3 grid((L.w + 245) / 246, (L.h + 15) / 16, n_frames);
+        hipLaunchKernelGGL(k_farn_polyexp_rows<16>, grid, dim3(256), 0, s, pyr, pyr_frame_stride, frame_slots, frame_R,
+                           frame_stride, L, pc);
+        return;
+    }
     const dim3 grid((L.w + 245) / 246, L.h, n_frames);
     hipLaunchKernelGGL(k_farn_polyexp, grid, dim3(256), 0, s, pyr, pyr_frame_stride, frame_slots, frame_R,
                        frame_stride, L, pc);

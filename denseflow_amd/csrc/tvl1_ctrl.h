@@ -131,3 +131,62 @@ DFX_HD void tvl1_end_segment(Tvl1State &s, const Tvl1LoopCfg &c, const Tvl1StepP
         s.seg_n0 = end_n + 1;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Tile geometry of one step of the default step kernel (k_tvl1_step_fused, 64 x TH tiles).
+//   geom bit 1: the halo is as wide as the step is long (a segment-final step of n < K iterations gets an n-pixel
+//               halo and owns (64-2n) x (TH-2n) pixels per tile);
+//   geom bit 0: tile columns start at x = 0 instead of -halo: the first tile also owns its left halo columns (the
+//               image border needs no halo) and the last one everything up to the right border.
+// The kernel, the launcher (grid size) and the CPU test of the ownership partition all use these functions.
+struct Tvl1StepGeom {
+    int halo;     // Kh
+    int ntx, nty; // tiles of this step
+    int shift;    // geom bit 0
+};
+
+DFX_HD Tvl1StepGeom tvl1_step_geom(int w, int h, int tw, int th, int K, int n_iters, int geom) {
+    Tvl1StepGeom g;
+    g.halo = (geom & 2) ? (n_iters < K ? n_iters : K) : K;
+    g.shift = geom & 1;
+    const int sw = tw - 2 * g.halo, sh = th - 2 * g.halo;
+    if (g.shift) {
+        const int n = (w - 2 * g.halo + sw - 1) / sw;
+        g.ntx = n > 1 ? n : 1;
+    } else {
+        g.ntx = (w + sw - 1) / sw;
+    }
+    g.nty = (h + sh - 1) / sh;
+    return g;
+}
+
+struct Tvl1TilePlace {
+    int x0, y0;         // image coordinates of the tile's lane 0 / row 0 (may be negative)
+    int own_lo, own_hi; // the tile also owns its left / right halo columns (image border)
+};
+
+DFX_HD Tvl1TilePlace tvl1_tile_place(const Tvl1StepGeom &g, int tw, int th, int tile) {
+    Tvl1TilePlace p;
+    const int ty = tile / g.ntx, tx = tile - ty * g.ntx;
+    const int sw = tw - 2 * g.halo, sh = th - 2 * g.halo;
+    p.x0 = g.shift ? tx * sw : tx * sw - g.halo;
+    p.y0 = ty * sh - g.halo;
+    p.own_lo = g.shift && tx == 0;
+    p.own_hi = g.shift && tx == g.ntx - 1;
+    return p;
+}
+
+// Is lane lx / row ly of a placed tile written back by this tile?  (Rows and columns outside the image are not.)
+DFX_HD bool tvl1_tile_owns(const Tvl1StepGeom &g, const Tvl1TilePlace &p, int tw, int th, int lx, int ly, int w, int h) {
+    const int gx = p.x0 + lx, gy = p.y0 + ly;
+    return (lx >= g.halo || p.own_lo) && (lx < tw - g.halo || p.own_hi) && ly >= g.halo && ly < th - g.halo &&
+           gx >= 0 && gx < w && gy >= 0 && gy < h;
+}
+
+// Workgroups per pair the launcher has to provide: the tile count of a full K-iteration step (shorter steps never
+// have more tiles).  With an in-kernel warp phase (classic tiling) the classic count is needed.
+DFX_HD int tvl1_step_grid(int w, int h, int tw, int th, int K, int geom, int split_warp) {
+    const Tvl1StepGeom full = tvl1_step_geom(w, h, tw, th, K, K, split_warp ? geom : (geom & ~1));
+    return full.ntx * full.nty;
+}
+

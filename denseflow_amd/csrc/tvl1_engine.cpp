@@ -20,7 +20,7 @@
 // Tile geometry of the default step kernel (k_tvl1_step_fused, Tvl1LevelCtx::geom): bit 0 = tile columns start at
 // x = 0, bit 1 = halo as wide as the step is long.
 #ifndef DFX_TVL1_GEOM_DEFAULT
-#define DFX_TVL1_GEOM_DEFAULT 0
+#define DFX_TVL1_GEOM_DEFAULT 3
 #endif
 
 namespace {

@@ -68,3 +68,39 @@ extern "C" int ctrl_replay_level_ex(const float *I0, const float *I1, float *u1,
     *steps_out = step_id;
     return 0;
 }
+
+// Ownership partition of a step's tile geometry (tvl1_step_geom / tvl1_tile_place / tvl1_tile_owns — the functions the
+// step kernel and its launcher use).  Returns 0 when (1) every image pixel is owned by exactly one tile, (2) every
+// owned pixel's dependency cone of `halo` pixels lies inside its tile or outside the image (so the tile's recomputed
+// values are the exact ones), (3) the step's tile count does not exceed the launched grid; otherwise a code > 0.
+extern "C" int ctrl_geometry_check(int w, int h, int tw, int th, int K, int n_iters, int geom, int split_warp,
+                                   int *n_tiles_out, int *grid_out) {
+    const Tvl1StepGeom g = tvl1_step_geom(w, h, tw, th, K, n_iters, geom);
+    const int nt = g.ntx * g.nty, grid = tvl1_step_grid(w, h, tw, th, K, geom, split_warp);
+    *n_tiles_out = nt;
+    *grid_out = grid;
+    if (nt > grid || nt < 1)
+        return 3;
+    if (g.halo != ((geom & 2) ? (n_iters < K ? n_iters : K) : K))
+        return 4;
+    std::vector<unsigned char> owner((size_t)w * h, 0);
+    for (int t = 0; t < nt; ++t) {
+        const Tvl1TilePlace p = tvl1_tile_place(g, tw, th, t);
+        for (int ly = 0; ly < th; ++ly)
+            for (int lx = 0; lx < tw; ++lx) {
+                if (!tvl1_tile_owns(g, p, tw, th, lx, ly, w, h))
+                    continue;
+                const int gx = p.x0 + lx, gy = p.y0 + ly;
+                if (owner[(size_t)gy * w + gx]++)
+                    return 1; // owned twice
+                const int xa = gx - g.halo < 0 ? 0 : gx - g.halo, xb = gx + g.halo > w - 1 ? w - 1 : gx + g.halo;
+                const int ya = gy - g.halo < 0 ? 0 : gy - g.halo, yb = gy + g.halo > h - 1 ? h - 1 : gy + g.halo;
+                if (xa < p.x0 || xb >= p.x0 + tw || ya < p.y0 || yb >= p.y0 + th)
+                    return 2; // would depend on a value the tile cannot recompute exactly
+            }
+    }
+    for (size_t i = 0; i < owner.size(); ++i)
+        if (owner[i] != 1)
+            return 5; // not owned at all
+    return 0;
+}

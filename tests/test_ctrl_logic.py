@@ -69,3 +69,32 @@ def test_state_machine_replays_oracle(oracle, harness, fuse_k, w, h, seed, dt, i
     assert steps.value <= int(iters[:5].sum()) + prm.warps
     if split_warp and iterations > 0:  # a warp no longer occupies a step of its own
         assert steps.value <= int(iters[:5].sum())
+
+
+@pytest.mark.parametrize("geom", [0, 1, 2, 3])
+def test_step_tile_geometry_partitions_the_image(harness, geom):
+    """The step kernel's optional tile geometries (tvl1_ctrl.h: tile columns from x = 0, halo as wide as the step is
+    long): every pixel has exactly one owning tile, owned pixels never depend on values outside their tile, and no
+    step needs more workgroups than the launcher provides — for the 1080p pyramid, degenerate sizes and random ones."""
+    harness.ctrl_geometry_check.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_int)] * 2
+    harness.ctrl_geometry_check.restype = C.c_int
+    rng = np.random.default_rng(7)
+    sizes = [(1920, 1080), (1536, 864), (1229, 691), (983, 553), (786, 442), (224, 224), (16, 16), (57, 40), (64, 64),
+             (56, 24), (60, 28), (65, 33), (1, 1), (63, 5), (128, 31), (120, 442)]
+    sizes += [(int(rng.integers(1, 400)), int(rng.integers(1, 200))) for _ in range(40)]
+    nt, grid = C.c_int(0), C.c_int(0)
+    for (w, h) in sizes:
+        for k in (1, 2, 3, 4, 6, 12):
+            for n in range(1, k + 1):
+                if w * h > 500_000 and (k != 4 or n not in (2, 4)):
+                    continue
+                for split in (0, 1):
+                    rc = harness.ctrl_geometry_check(w, h, 64, 32, k, n, geom, split, C.byref(nt), C.byref(grid))
+                    assert rc == 0, (w, h, k, n, geom, split, rc, nt.value, grid.value)
+    # what the geometries buy at the 1080p pyramid (K = 4): tile counts of a full step and of a 2-iteration step
+    want = {0: (285, 285), 1: (266, 266), 2: (285, 224), 3: (266, 224)}[geom]
+    got = []
+    for n in (4, 2):
+        assert harness.ctrl_geometry_check(786, 442, 64, 32, 4, n, geom, 1, C.byref(nt), C.byref(grid)) == 0
+        got.append(nt.value)
+    assert tuple(got) == want

@@ -102,3 +102,25 @@ def test_device_resident_entry_point(dfx):
         got = d_flows.cpu().numpy()
     for i in range(n - 1):
         assert np.array_equal(got[i], host[i])
+
+
+@pytest.mark.parametrize("w,h,seed", [(256, 128, 3), (640, 360, 4), (97, 61, 9), (33, 40, 2), (1920, 1080, 2)])
+def test_frame_preparation_variants_do_not_change_a_bit(dfx, oracle, w, h, seed, monkeypatch):
+    """Two restructurings of the per-frame kernels keep every bit: bilinear pyramid taps whose weight is exactly 0 are
+    not evaluated (DFX_FARN_SKIP0: 3 of 4 taps wherever the level's size divides the frame's), and the polynomial
+    expansion walks 16 rows per workgroup with its vertical window in registers (DFX_FARN_POLYROWS)."""
+    clip = SynthClip(w, h, seed)
+    frames = clip.frames(4)
+    monkeypatch.setenv("DFX_FARN_SKIP0", "0")
+    monkeypatch.setenv("DFX_FARN_POLYROWS", "0")
+    with dfx.FlowEngine(w, h, "farn", max_batch=2) as eng:
+        base = eng.calc_optflows(frames, 1)
+    if w * h <= 640 * 360:
+        assert np.array_equal(base[0], oracle.farneback_calc(frames[0], frames[1]))
+    for skip, rows in ((1, 0), (0, 16), (1, 16)):
+        monkeypatch.setenv("DFX_FARN_SKIP0", str(skip))
+        monkeypatch.setenv("DFX_FARN_POLYROWS", str(rows))
+        with dfx.FlowEngine(w, h, "farn", max_batch=2) as eng:
+            out = eng.calc_optflows(frames, 1)
+        for i, (a, b) in enumerate(zip(out, base)):
+            assert np.array_equal(a, b), f"skip0={skip} polyrows={rows}: pair {i} changed"
