@@ -22,12 +22,13 @@ i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 def harness(oracle):
     out_dir = os.path.join(HERE, "_build")
     os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "libctrl_harness.so")
+    so = os.path.join(out_dir, "libctrl_harness.%d.so" % os.getpid())  # per process: pytest-xdist workers build in parallel
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so,
            os.path.join(HERE, "ctrl_harness.cpp"), os.path.join(ROOT, "oracle", "liboracle.so"),
            "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
     subprocess.run(cmd, check=True, capture_output=True)
     L = C.CDLL(so)
+    os.unlink(so)  # the mapping stays valid
     L.ctrl_replay_level.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                     C.c_double, C.c_double, C.c_double, i32p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.ctrl_replay_level.restype = C.c_int
