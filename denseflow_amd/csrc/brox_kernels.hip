@@ -149,7 +149,8 @@ __device__ __forceinline__ float bl_sample(const float *p, const BlTap &t) {
 // max(x-1, 0) / min(x+1, w-1) addressing of the definition) in LDS instead of 56 global loads per pixel.
 __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set, int d_set) {
     __shared__ float WUs[6][68], WVs[6][68];
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const DfxBlockXY blk = dfx_block_xy(); // 1-pixel ring + warped samples shared with the rows above / below: one L2
+    const int x0 = blk.x * 64, y0 = blk.y * 4;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int x = x0 + lx, y = y0 + ly;
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(BROX_TW *BROX_TH / 4) void k_brox_sor_fused(BroxLev
     __shared__ float WU[BROX_TH][BROX_TW];
     __shared__ float WV[BROX_TH][BROX_TW];
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int tile = dfx_block_linear(); // neighbouring tiles re-read each other's 2*S-pixel halo: keep them in one L2
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int x0 = tx * (BROX_TW - 2 * BROX_HALO) - BROX_HALO; // even
     const int y0 = ty * (BROX_TH - 2 * BROX_HALO) - BROX_HALO; // even
     const int pcol = threadIdx.x % (BROX_TW / 2), prow = threadIdx.x / (BROX_TW / 2);

@@ -72,3 +72,43 @@ struct Tvl1LevelCtx {
 };
 
 static inline int dfx_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+// XCD-aware workgroup -> tile mapping (device code only).  MI355X has 8 XCDs with a private 4 MiB L2 each and the
+// dispatcher is observed to place workgroup b of a launch on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"):
+// with the plain blockIdx -> tile mapping the neighbours of a tile — whose halo, box-filter or gather footprint
+// overlaps its own — run on seven OTHER XCDs and every L2 fetches the shared rows for itself.  dfx_block_xy() hands
+// each XCD one contiguous run of the (x, y) tiles of a grid instead (row-major, bijective for any tile count; grid.z
+// = pair / frame is left alone).  A speed choice only: nothing depends on where a workgroup runs.
+#if defined(__HIPCC__)
+#ifndef DFX_XCD_REMAP
+#define DFX_XCD_REMAP 1 // 0: plain blockIdx (A/B builds, scripts/build_variant.sh)
+#endif
+struct DfxBlockXY {
+    int x, y;
+};
+__device__ __forceinline__ DfxBlockXY dfx_block_xy() {
+    DfxBlockXY r;
+    r.x = (int)blockIdx.x;
+    r.y = (int)blockIdx.y;
+#if DFX_XCD_REMAP
+    const int gx = (int)gridDim.x, nt = gx * (int)gridDim.y;
+    const int lin = r.y * gx + r.x, q = nt >> 3, rem = nt & 7, k = lin & 7;
+    const int t = k * q + (k < rem ? k : rem) + (lin >> 3);
+    r.y = t / gx;
+    r.x = t - r.y * gx;
+#endif
+    return r;
+}
+// the same for a grid whose x dimension already is a linear tile index
+__device__ __forceinline__ int dfx_block_linear() {
+    const int id = (int)blockIdx.x;
+#if DFX_XCD_REMAP
+    const int nt = (int)gridDim.x, q = nt >> 3, rem = nt & 7, k = id & 7;
+    return k * q + (k < rem ? k : rem) + (id >> 3);
+#else
+    return id;
+#endif
+}
+#endif
+

@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 
+#include "dfx_device.h"
 #include "farneback_kernels.h"
 
 #define FARN_HALF_MAX 8 // box half-width supported by the fused iteration kernel (winSize <= 17)
@@ -59,8 +60,9 @@ __global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ f
     // one thread = one column of one destination row: BOTH source rows the bilinear resize samples (y1, y1 + 1).
     // Their tap windows overlap in all but one row each, so the interior path loads 2 values per tap pair for the
     // two outputs (a rolling pair of registers supplies the other two) instead of 4.
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const DfxBlockXY blk = dfx_block_xy(); // the tap windows of neighbouring rows overlap: keep them in one L2
+    const int x = blk.x * 64 + (threadIdx.x & 63);
+    const int dy = blk.y * 4 + (threadIdx.x >> 6);
     if (x >= W || dy >= dst_h)
         return;
     const float sy = (float)dy * ify;
@@ -237,8 +239,9 @@ __global__ __launch_bounds__(256) void k_farn_polyexp_rows(const float *__restri
     constexpr int N = 5;
     __shared__ float row[2][3][256];
     const int tx = threadIdx.x;
-    const int y0 = blockIdx.y * ROWS;
-    const int x = blockIdx.x * (256 - 2 * N) + tx - N;
+    const DfxBlockXY blk = dfx_block_xy();
+    const int y0 = blk.y * ROWS;
+    const int x = blk.x * (256 - 2 * N) + tx - N;
     const float *src = pyr + (long long)blockIdx.z * pyr_frame_stride;
     const int xw = min(max(x, 0), L.w - 1);
     const bool writes = tx >= N && tx + N < 256 && x < L.w;
@@ -398,8 +401,9 @@ __device__ __forceinline__ void update_matrices_px(const float *R0, const float 
 }
 
 __global__ __launch_bounds__(256) void k_farn_update_matrices(FarnPairCtx c, int flow_set, int m_set) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const DfxBlockXY blk = dfx_block_xy(); // bilinear gathers of R1 around (x + dx, y + dy): neighbours share rows
+    const int x = blk.x * 64 + (threadIdx.x & 63);
+    const int y = blk.y * 4 + (threadIdx.x >> 6);
     if (x >= c.L.w || y >= c.L.h)
         return;
     const int b = blockIdx.z;
@@ -513,7 +517,8 @@ __global__ __launch_bounds__(256) void k_farn_iteration_t(FarnPairCtx c, int flo
     __shared__ __attribute__((aligned(16))) float hb[TH][HP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const DfxBlockXY blk = dfx_block_xy(); // the 76 x 44 halo tiles of neighbours overlap (M is read 1.63 x): one L2
+    const int x0 = blk.x * TW, y0 = blk.y * TH;
     const int w = c.L.w, h = c.L.h, pitch = c.L.pitch;
 
     // clamped source offsets of this thread's halo-tile elements: the same for all five planes

@@ -30,10 +30,6 @@ for cfg in configs:
         os.environ["DFX_TVL1_GEOM"] = str(parts[4])
     if len(parts) > 5:  # fused-SOR barrier scheme (brox) — read per launch
         os.environ["DFX_BROX_SOR"] = str(parts[5])
-    if len(parts) > 8:  # warp kernel: strips per workgroup (tvl1) — read per launch
-        os.environ["DFX_TVL1_WARP_SPW"] = str(parts[8])
-    if len(parts) > 9:  # warp kernel: gradient of I1 at the taps (tvl1) — read per launch
-        os.environ["DFX_TVL1_WARP_OTF"] = str(parts[9])
     if len(parts) > 6:  # zero-weight pyramid taps skipped (farn) — read per launch
         os.environ["DFX_FARN_SKIP0"] = str(parts[6])
     if len(parts) > 7:  # rows per workgroup of the polynomial expansion (farn) — read per launch
