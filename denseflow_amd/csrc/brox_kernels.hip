@@ -57,8 +57,9 @@ __global__ __launch_bounds__(256) void k_brox_u8_to_f32(const unsigned char *src
 __global__ __launch_bounds__(256) void k_brox_downsample(float *frames, long long frame_stride, const int *frame_slots,
                                                          long long src_off, int sw, int sh, int spitch,
                                                          long long dst_off, int dw, int dh, int dpitch, float factor) {
-    const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const DfxBlockXY blk = dfx_block_xy(); // XCD-aware (dfx_device.h): neighbouring rows share one L2
+    const int ix = blk.x * 64 + (threadIdx.x & 63);
+    const int iy = blk.y * 4 + (threadIdx.x >> 6);
     if (ix >= dw || iy >= dh)
         return;
     float *base = frames + (long long)frame_slots[blockIdx.z] * frame_stride;
@@ -84,8 +85,9 @@ __global__ __launch_bounds__(256) void k_brox_downsample(float *frames, long lon
 __global__ __launch_bounds__(256) void k_brox_deriv(float *frames, long long frame_stride, const int *frame_slots,
                                                     long long src_off, long long dst_off, int w, int h, int pitch,
                                                     int axis) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const DfxBlockXY blk = dfx_block_xy(); // XCD-aware (dfx_device.h): neighbouring rows share one L2
+    const int x = blk.x * 64 + (threadIdx.x & 63);
+    const int y = blk.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h)
         return;
     float *base = frames + (long long)frame_slots[blockIdx.z] * frame_stride;
@@ -425,8 +427,9 @@ __global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int 
 
 __global__ __launch_bounds__(256) void k_brox_prolongate(BroxLevelCtx c, int uv_set, int dw, int dh, int dpitch,
                                                          float factor, float mul) {
-    const int ix = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const DfxBlockXY blk = dfx_block_xy(); // XCD-aware (dfx_device.h): neighbouring rows share one L2
+    const int ix = blk.x * 64 + (threadIdx.x & 63);
+    const int iy = blk.y * 4 + (threadIdx.x >> 6);
     if (ix >= dw || iy >= dh)
         return;
     const int b = blockIdx.z, sw = c.w, sh = c.h;

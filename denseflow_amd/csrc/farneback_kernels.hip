@@ -130,8 +130,9 @@ __global__ __launch_bounds__(256) void k_farn_blur_h_resize(const float *__restr
                                                             const float *__restrict__ ker, int half,
                                                             float *__restrict__ pyr, long long pyr_frame_stride,
                                                             int skip_zero_weights) {
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const DfxBlockXY blk = dfx_block_xy(); // XCD-aware (dfx_device.h): neighbouring rows share one L2
+    const int dx = blk.x * 64 + (threadIdx.x & 63);
+    const int dy = blk.y * 4 + (threadIdx.x >> 6);
     if (dx >= dst_w || dy >= dst_h)
         return;
     const float sx = (float)dx * ifx, sy = (float)dy * ify;
@@ -321,8 +322,9 @@ __device__ __forceinline__ float resize_linear_px_f(const float *src, int sw, in
 
 __global__ __launch_bounds__(256) void k_farn_init_flow(FarnPairCtx c, int cur_set, int prev_w, int prev_h,
                                                         int prev_pitch, float ifx, float ify, float up, int zero) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const DfxBlockXY blk = dfx_block_xy(); // XCD-aware (dfx_device.h): neighbouring rows share one L2
+    const int x = blk.x * 64 + (threadIdx.x & 63);
+    const int y = blk.y * 4 + (threadIdx.x >> 6);
     if (x >= c.L.w || y >= c.L.h)
         return;
     const int b = blockIdx.z;

@@ -11,12 +11,12 @@ ALGOS=${ALGOS:-"tvl1 farn"}
 cd /tmp
 for A in $ALGOS; do
 for CNT in FETCH_SIZE WRITE_SIZE; do
-  ( timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $R/gpurun_out/pmc_${A}_$CNT -o p -- python $R/bench.py --algo $A --steps 1 --warmup 0 --frames 34 --max-batch 16 --no-cpu-baseline ) > $R/gpurun_out/pmc_${A}_$CNT.log 2>&1; echo "pmc $A $CNT rc=$?"
+  ( timeout -s KILL ${PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc $CNT --output-format csv -d $R/gpurun_out/pmc_${A}_$CNT -o p -- python $R/bench.py --algo $A --steps 1 --warmup 0 --frames 34 --max-batch 16 --no-cpu-baseline ) > $R/gpurun_out/pmc_${A}_$CNT.log 2>&1; echo "pmc $A $CNT rc=$?"
 done; done
 cd $R
 ALGOS="$ALGOS" python - <<'PY'
 import csv,glob,collections,json,os
-dom={"tvl1":"void k_tvl1_step_fused<32, 4, true, 3, true>","farn":"void k_farn_iteration_t<6>","brox":"void k_brox_sor_fused<64, 64, 5>"}
+dom={"tvl1":"void k_tvl1_step_fused<32, 4, true, 3, true>","farn":"void k_farn_iteration_t<6>","brox":"void k_brox_sor_fused<64, 64, 5, 2>"}
 out={}
 for A in os.environ["ALGOS"].split():
     per={}
