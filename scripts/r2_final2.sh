@@ -46,6 +46,8 @@ for P in "A SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
   ( SWEEP="0:4:16:0" timeout -s KILL 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/sq_$T -o p -- python $R/scripts/sweep_tvl1.py 1920 1080 17 ) > $O/sq_$T.log 2>&1; echo "sq $T rc=$?"
   python $R/scripts/sq_summary.py $O/sq_$T step_fused > $O/sq_final_kernel_$T.json 2>>$O/sq_$T.log; rm -rf $O/sq_$T
 done
+( ALGO=brox SWEEP="0:0:8:0" timeout -s KILL 150 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/sq_brox -o p -- python $R/scripts/sweep_tvl1.py 1920 1080 9 ) > $O/sq_brox.log 2>&1; echo "sq brox rc=$?"
+python $R/scripts/sq_summary.py $O/sq_brox k_brox_sor_fused > $O/sq_brox_sor_final_A.json 2>>$O/sq_brox.log; rm -rf $O/sq_brox
 cd $R
 for f in $O/bench_*.json; do echo "== $f"; python - "$f" <<'PY'
 import json,sys
