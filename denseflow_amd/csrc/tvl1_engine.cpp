@@ -161,8 +161,6 @@ int Tvl1Engine::create() {
     // batch: enough pairs that the coarse levels fill 256 CUs, bounded by memory
     const long long plane = (long long)lv[0].pitch * c->H;
     plane_stride = plane;
-    if (const char *g = std::getenv("DFX_TVL1_PLANE_SKEW")) // measurement switch: floats added to the plane stride
-        plane_stride = plane + std::max(0, std::atoi(g)) / 64 * 64;
     slot_stride = plane_stride * PL_COUNT;
     B = p.max_batch;
     if (B <= 0) {

@@ -30,8 +30,6 @@ for cfg in configs:
         os.environ["DFX_TVL1_GEOM"] = str(parts[4])
     if len(parts) > 5:  # fused-SOR barrier scheme (brox) — read per launch
         os.environ["DFX_BROX_SOR"] = str(parts[5])
-    if len(parts) > 8:  # measurement switch: floats added to the TVL1 plane stride — read by dfx_create
-        os.environ["DFX_TVL1_PLANE_SKEW"] = str(parts[8])
     if len(parts) > 6:  # zero-weight pyramid taps skipped (farn) — read per launch
         os.environ["DFX_FARN_SKIP0"] = str(parts[6])
     if len(parts) > 7:  # rows per workgroup of the polynomial expansion (farn) — read per launch
