@@ -17,6 +17,7 @@ cd $R
 ALGOS="$ALGOS" python - <<'PY'
 import csv,glob,collections,json,os
 dom={"tvl1":"void k_tvl1_step_fused<32, 4, true, 3, true>","farn":"void k_farn_iteration_t<6>","brox":"void k_brox_sor_fused<64, 64, 5, 2>"}
+comp={"tvl1":"void k_tvl1_warp<5>"}  # launched in front of every step launch: one pair of launches per step
 out={}
 for A in os.environ["ALGOS"].split():
     per={}
@@ -31,12 +32,18 @@ for A in os.environ["ALGOS"].split():
         for k,v in sorted(agg.items(), key=lambda kv:-kv[1][1])[:5]:
             print(A,CNT,k[:50],v)
         per[CNT]=agg.get(dom[A])
+        if A in comp: per["c_"+CNT]=agg.get(comp[A])
     if per.get("FETCH_SIZE") and per.get("WRITE_SIZE"):
         n=per["FETCH_SIZE"][0]; f=per["FETCH_SIZE"][1]/n; w=per["WRITE_SIZE"][1]/per["WRITE_SIZE"][0]
         b=(2*f+w)*1024
         out[A]={"kernel":dom[A],"launches":n,"FETCH_SIZE_KB_per_launch":f,"WRITE_SIZE_KB_per_launch":w,
                 "hbm_bytes_per_launch":b,"measured_batch":16,"hbm_bytes_per_launch_per_pair":b/16,
                 "workload":"1920x1080, 34 frames (33 pairs, batches of 16/16/1), 1 GPU"}
+        if per.get("c_FETCH_SIZE") and per.get("c_WRITE_SIZE"):
+            cf=per["c_FETCH_SIZE"][1]/per["c_FETCH_SIZE"][0]; cw=per["c_WRITE_SIZE"][1]/per["c_WRITE_SIZE"][0]
+            out[A].update({"companion_kernel":comp[A],"companion_launches":per["c_FETCH_SIZE"][0],
+                           "companion_FETCH_SIZE_KB_per_launch":cf,"companion_WRITE_SIZE_KB_per_launch":cw,
+                           "companion_hbm_bytes_per_launch_per_pair":(2*cf+cw)*1024/16})
 json.dump(out,open("gpurun_out/pmc_traffic.json","w"),indent=1)
 print(json.dumps(out,indent=1))
 PY
