@@ -80,6 +80,13 @@ static inline int dfx_round_up(int v, int m) { return (v + m - 1) / m * m; }
 // overlaps its own — run on seven OTHER XCDs and every L2 fetches the shared rows for itself.  dfx_block_xy() hands
 // each XCD one contiguous run of the (x, y) tiles of a grid instead (row-major, bijective for any tile count; grid.z
 // = pair / frame is left alone).  A speed choice only: nothing depends on where a workgroup runs.
+// Tile index of the workgroup with dispatch index `lin` among `nt`: workgroups lin = k, k + 8, k + 16 ... (XCD k) get the
+// contiguous tiles [k*q + min(k, r), ...) with q = nt / 8, r = nt % 8 — a bijection of [0, nt) for every nt (checked on
+// the CPU: tests/test_ctrl_logic.py).  Plain C++ so that the test compiles the very function the kernels use.
+DFX_HD int dfx_xcd_tile_index(int lin, int nt) {
+    const int q = nt >> 3, rem = nt & 7, k = lin & 7;
+    return k * q + (k < rem ? k : rem) + (lin >> 3);
+}
 #if defined(__HIPCC__)
 #ifndef DFX_XCD_REMAP
 #define DFX_XCD_REMAP 1 // 0: plain blockIdx (A/B builds, scripts/build_variant.sh)
@@ -92,9 +99,8 @@ __device__ __forceinline__ DfxBlockXY dfx_block_xy() {
     r.x = (int)blockIdx.x;
     r.y = (int)blockIdx.y;
 #if DFX_XCD_REMAP
-    const int gx = (int)gridDim.x, nt = gx * (int)gridDim.y;
-    const int lin = r.y * gx + r.x, q = nt >> 3, rem = nt & 7, k = lin & 7;
-    const int t = k * q + (k < rem ? k : rem) + (lin >> 3);
+    const int gx = (int)gridDim.x;
+    const int t = dfx_xcd_tile_index(r.y * gx + r.x, gx * (int)gridDim.y);
     r.y = t / gx;
     r.x = t - r.y * gx;
 #endif
@@ -102,12 +108,10 @@ __device__ __forceinline__ DfxBlockXY dfx_block_xy() {
 }
 // the same for a grid whose x dimension already is a linear tile index
 __device__ __forceinline__ int dfx_block_linear() {
-    const int id = (int)blockIdx.x;
 #if DFX_XCD_REMAP
-    const int nt = (int)gridDim.x, q = nt >> 3, rem = nt & 7, k = id & 7;
-    return k * q + (k < rem ? k : rem) + (id >> 3);
+    return dfx_xcd_tile_index((int)blockIdx.x, (int)gridDim.x);
 #else
-    return id;
+    return (int)blockIdx.x;
 #endif
 }
 #endif

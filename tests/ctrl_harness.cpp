@@ -104,3 +104,18 @@ extern "C" int ctrl_geometry_check(int w, int h, int tw, int th, int K, int n_it
             return 5; // not owned at all
     return 0;
 }
+
+// dfx_xcd_tile_index (dfx_device.h, the workgroup -> tile mapping of every kernel that reads a neighbourhood): a bijection
+// of [0, nt), and the workgroups of one dispatch class (lin % 8) get one contiguous run of tiles.
+#include "../denseflow_amd/csrc/dfx_device.h"
+extern "C" int ctrl_xcd_map_check(int nt) {
+    std::vector<int> seen((size_t)nt, 0);
+    for (int lin = 0; lin < nt; ++lin) {
+        const int t = dfx_xcd_tile_index(lin, nt);
+        if (t < 0 || t >= nt || seen[(size_t)t]++)
+            return 1;
+        if (lin >= 8 && t != dfx_xcd_tile_index(lin - 8, nt) + 1)
+            return 2; // the next workgroup of the same class takes the next tile
+    }
+    return 0;
+}

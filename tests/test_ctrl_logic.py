@@ -99,3 +99,12 @@ def test_step_tile_geometry_partitions_the_image(harness, geom):
         assert harness.ctrl_geometry_check(786, 442, 64, 32, 4, n, geom, 1, C.byref(nt), C.byref(grid)) == 0
         got.append(nt.value)
     assert tuple(got) == want
+
+
+def test_xcd_aware_tile_mapping_is_a_bijection(harness):
+    """dfx_xcd_tile_index: every tile of a grid is visited exactly once for every tile count (a kernel that skipped or
+    doubled a tile would still produce plausible output elsewhere), and each dispatch class gets a contiguous run."""
+    harness.ctrl_xcd_map_check.argtypes = [C.c_int]
+    harness.ctrl_xcd_map_check.restype = C.c_int
+    for nt in list(range(1, 300)) + [1020, 1100, 1248, 1575, 2040, 30 * 270, 65537]:
+        assert harness.ctrl_xcd_map_check(nt) == 0, nt
