@@ -4,6 +4,7 @@
 // Fixed control flow: a pair is a straight sequence of launches, `batch` pairs share each launch
 // (grid.z = pair); a frame's pyramid and its five derivative pyramids are built once and serve two pairs.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "brox_kernels.h"
@@ -39,6 +40,7 @@ class BroxEngine final : public AlgoEngine {
     float *d_frames = nullptr;
     int *d_frame_slots = nullptr, *h_slots_pinned = nullptr;
     int B = 0;
+    int sor_mode = 0; // barrier scheme of the fused SOR (k_brox_sor_fused MODE), fixed when the engine is created
     float *d_planes = nullptr;
     long long plane_stride = 0, slot_stride = 0;
     PairDesc *d_pairs = nullptr, *h_pairs_pinned = nullptr;
@@ -62,6 +64,9 @@ void BroxEngine::destroy() {
 
 int BroxEngine::create() {
     const dfx_params &p = c->prm;
+    sor_mode = brox_sor_mode_default();
+    if (const char *e = std::getenv("DFX_BROX_SOR")) // A/B switch of the measurements and the parity tests
+        sor_mode = std::atoi(e);
     if (!(p.brox_scale_factor > 0.f && p.brox_scale_factor < 1.f) || !(p.brox_alpha > 0.f) ||
         p.brox_inner_iterations < 0 || p.brox_outer_iterations < 1 || p.brox_solver_iterations < 0)
         return dfx_fail(c, DFX_ERR_INVALID, "invalid Brox parameters");
@@ -186,7 +191,8 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
             } else {
                 const int S = brox_fused_sweeps(p.tvl1_tile_h);
                 for (int si = 0; si < p.brox_solver_iterations; si += S) {
-                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si), p.tvl1_tile_h);
+                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si), p.tvl1_tile_h,
+                                          sor_mode);
                     ds ^= 1; // it wrote the other set
                 }
             }

@@ -518,13 +518,13 @@ static void sor_launch(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_s
     hipLaunchKernelGGL((k_brox_sor_fused<TW, TH, S, MODE>), dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(TW * TH / 4), 0,
                        s, c, uv_set, d_src, n_sweeps, tiles_x);
 }
-void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int cfg) {
+int brox_sor_mode_default() { return BROX_SOR_MODE_DEFAULT; }
+// mode: barrier scheme of the default tile (k_brox_sor_fused MODE); the engine reads the A/B switch DFX_BROX_SOR once
+// when it is created
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int cfg,
+                           int mode) {
     int tw, th, S;
     sor_cfg(cfg, tw, th, S);
-    // barrier scheme of the default tile (k_brox_sor_fused MODE); DFX_BROX_SOR is the A/B switch of the measurements
-    // and parity tests, looked up per launch so that one process can compare the modes
-    const char *e = getenv("DFX_BROX_SOR");
-    const int mode = e ? atoi(e) : BROX_SOR_MODE_DEFAULT;
     if (tw == 128)
         sor_launch<128, 32, 2>(s, c, uv_set, d_src, n_sweeps);
     else if (th == 32)

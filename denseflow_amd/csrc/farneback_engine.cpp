@@ -7,6 +7,7 @@
 // the frame belongs to.
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 
 #include "dfx_internal.h"
@@ -136,6 +137,7 @@ class FarnebackEngine final : public AlgoEngine {
     int *h_slots_pinned = nullptr;
     // scratch for frame preparation, sized for n_frame_slots frames
     float *d_f32 = nullptr, *d_tmpv = nullptr, *d_pyr = nullptr;
+    int skip_zero_weights = 1, polyexp_rows = 16; // frame-preparation forms, fixed when the engine is created
 
     int B = 0;
     float *d_planes = nullptr;
@@ -165,6 +167,12 @@ void FarnebackEngine::destroy() {
 
 int FarnebackEngine::create() {
     const dfx_params &p = c->prm;
+    skip_zero_weights = farn_skip_zero_weights_default();
+    polyexp_rows = farn_polyexp_rows_default();
+    if (const char *e = std::getenv("DFX_FARN_SKIP0")) // A/B switches of the measurements and the parity tests
+        skip_zero_weights = std::atoi(e);
+    if (const char *e = std::getenv("DFX_FARN_POLYROWS"))
+        polyexp_rows = std::atoi(e);
     if (p.farn_poly_n != 5)
         return dfx_fail(c, DFX_ERR_UNSUPPORTED, "Farneback: only polyN = 5 (the reference's default) is built");
     if (p.farn_flags != 0)
@@ -268,10 +276,10 @@ int FarnebackEngine::build_frames(const unsigned char *d_src, long long src_fram
     for (int k = nlev - 1; k >= 0; --k) {
         const FLevel &L = lv[k];
         farn_launch_blur_v(c->stream, d_f32, plane_stride, n, W, H, pitch0, L.g.h, L.ify, d_gker + L.ker_off, L.half,
-                           d_tmpv, plane_stride * 2);
+                           d_tmpv, plane_stride * 2, skip_zero_weights);
         farn_launch_blur_h_resize(c->stream, d_tmpv, plane_stride * 2, n, W, H, pitch0, L.g.w, L.g.h, L.g.pitch, L.ifx,
-                                  L.ify, d_gker + L.ker_off, L.half, d_pyr, plane_stride);
-        farn_launch_polyexp(c->stream, d_pyr, plane_stride, n, d_frame_slots, d_R, frame_elems, L.g, pc);
+                                  L.ify, d_gker + L.ker_off, L.half, d_pyr, plane_stride, skip_zero_weights);
+        farn_launch_polyexp(c->stream, d_pyr, plane_stride, n, d_frame_slots, d_R, frame_elems, L.g, pc, polyexp_rows);
     }
     c->stats.kernel_launches += 1 + 3 * nlev;
     return DFX_OK;

@@ -42,15 +42,19 @@ void farn_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long sr
 // vertical Gaussian pass at the 2 source rows every destination row samples (B.4 + E.1 fused)
 void farn_launch_blur_v(hipStream_t s, const float *frames, long long frame_stride, int n_frames, int W, int H,
                         int pitch0, int dst_h, float ify, const float *ker_half, int half, float *tmpv,
-                        long long tmpv_frame_stride);
+                        long long tmpv_frame_stride, int skip_zero_weights);
 // horizontal Gaussian pass at the 2 source columns every destination pixel samples + bilinear resize
 void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_frame_stride, int n_frames, int W,
                                int H, int pitch0, int dst_w, int dst_h, int dst_pitch, float ifx, float ify,
-                               const float *ker_half, int half, float *pyr, long long pyr_frame_stride);
+                               const float *ker_half, int half, float *pyr, long long pyr_frame_stride,
+                               int skip_zero_weights);
 // polynomial expansion (B.5) of n_frames level images into their frame slots
 void farn_launch_polyexp(hipStream_t s, const float *pyr, long long pyr_frame_stride, int n_frames,
                          const int *frame_slots, float *frame_R, long long frame_stride, FarnLevelGeom L,
-                         FarnPolyConsts pc);
+                         FarnPolyConsts pc, int rows_per_workgroup);
+// the defaults of the two frame-preparation switches (the engine reads DFX_FARN_SKIP0 / DFX_FARN_POLYROWS once at creation)
+int farn_skip_zero_weights_default();
+int farn_polyexp_rows_default();
 // flow(level k) = resize(flow(level k+1)) * (1/pyrScale), or zero at the coarsest level
 void farn_launch_init_flow(hipStream_t s, const FarnPairCtx &c, int cur_set, int prev_w, int prev_h, int prev_pitch,
                            float ifx, float ify, float up, int zero);

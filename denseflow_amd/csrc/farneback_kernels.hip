@@ -653,40 +653,37 @@ void farn_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long sr
                        dst, dst_frame_stride, w, h, pitch);
 }
 
-// Zero-weight taps of the pyramid resize are not evaluated (k_farn_blur_v / k_farn_blur_h_resize); DFX_FARN_SKIP0 is
-// the A/B switch of the measurements and the parity test, looked up per launch.
+// Zero-weight taps of the pyramid resize are not evaluated (k_farn_blur_v / k_farn_blur_h_resize) and the polynomial
+// expansion walks 16 rows per workgroup: the defaults of the engine's two frame-preparation switches.
 #ifndef FARN_POLYROWS_DEFAULT
 #define FARN_POLYROWS_DEFAULT 16
 #endif
 #ifndef FARN_SKIP0_DEFAULT
 #define FARN_SKIP0_DEFAULT 1
 #endif
-static int farn_skip_zero_weights() {
-    const char *e = getenv("DFX_FARN_SKIP0");
-    return e ? atoi(e) : FARN_SKIP0_DEFAULT;
-}
+int farn_skip_zero_weights_default() { return FARN_SKIP0_DEFAULT; }
+int farn_polyexp_rows_default() { return FARN_POLYROWS_DEFAULT; }
 
 void farn_launch_blur_v(hipStream_t s, const float *frames, long long frame_stride, int n_frames, int W, int H,
                         int pitch0, int dst_h, float ify, const float *ker_half, int half, float *tmpv,
-                        long long tmpv_frame_stride) {
+                        long long tmpv_frame_stride, int skip_zero_weights) {
     hipLaunchKernelGGL(k_farn_blur_v, grid64x4(W, dst_h, n_frames), dim3(256), 0, s, frames, frame_stride, W, H,
-                       pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride, farn_skip_zero_weights());
+                       pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride, skip_zero_weights);
 }
 
 void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_frame_stride, int n_frames, int W,
                                int H, int pitch0, int dst_w, int dst_h, int dst_pitch, float ifx, float ify,
-                               const float *ker_half, int half, float *pyr, long long pyr_frame_stride) {
+                               const float *ker_half, int half, float *pyr, long long pyr_frame_stride,
+                               int skip_zero_weights) {
     hipLaunchKernelGGL(k_farn_blur_h_resize, grid64x4(dst_w, dst_h, n_frames), dim3(256), 0, s, tmpv,
                        tmpv_frame_stride, W, H, pitch0, dst_w, dst_h, dst_pitch, ifx, ify, ker_half, half, pyr,
-                       pyr_frame_stride, farn_skip_zero_weights());
+                       pyr_frame_stride, skip_zero_weights);
 }
 
 void farn_launch_polyexp(hipStream_t s, const float *pyr, long long pyr_frame_stride, int n_frames,
                          const int *frame_slots, float *frame_R, long long frame_stride, FarnLevelGeom L,
-                         FarnPolyConsts pc) {
-    // DFX_FARN_POLYROWS (A/B switch, looked up per launch): 0 = one image row per workgroup, 16 = k_farn_polyexp_rows<16>
-    const char *e = getenv("DFX_FARN_POLYROWS");
-    const int rows = e ? atoi(e) : FARN_POLYROWS_DEFAULT;
+                         FarnPolyConsts pc, int rows) {
+    // rows: 16 = k_farn_polyexp_rows<16>, anything else = one image row per workgroup (the first form)
     if (rows == 16) {
         const dim3 grid((L.w + 245) / 246, (L.h + 15) / 16, n_frames);
         hipLaunchKernelGGL(k_farn_polyexp_rows<16>, grid, dim3(256), 0, s, pyr, pyr_frame_stride, frame_slots, frame_R,
