@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py's `cpu_baseline` leg, run as a child process — TEST / BENCH INFRASTRUCTURE ONLY.
 
-    python oracle/cpu_bench_child.py <frames.npy> <kind> <budget_s>
+    python oracle/cpu_bench_child.py <frames.npy> <kind> <budget_s> [min_pairs]
         kind = cpu_tvl1 : oracle/cpu_tvl1_baseline.c, the restatement of CPU cv::optflow::DualTVL1OpticalFlow
                           (the comparator BASELINE.json's north_star names), built here with -O3 -march=native
                tvl1 | farn | brox : the parity oracle (cv::cuda semantics), timed as a second CPU point
@@ -62,6 +62,7 @@ def cgroup_cpu_quota():
 
 def main():
     path, kind, budget = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    min_pairs = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # >= 10 pairs for the headline comparator
     allowed = os.sched_getaffinity(0)
     cpus = physical_cores(allowed)
     quota = cgroup_cpu_quota()
@@ -94,7 +95,7 @@ def main():
     t0 = time.perf_counter()
     fn(frames[0], frames[1])  # warm-up: thread team, page faults, table construction
     t1 = time.perf_counter() - t0
-    n = int(max(1, min(len(frames) - 1, (budget / 3.0) // max(t1, 1e-3))))
+    n = int(min(len(frames) - 1, max(min_pairs, 1, (budget / 3.0) // max(t1, 1e-3))))
     runs = []
     for _ in range(3):
         t0 = time.perf_counter()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Do HBM-bound launches (warps, 2-iteration steps) of one batch overlap VALU-bound launches (full steps) of another
 when two or three handles work on one GPU from separate host threads (private streams)?
-Usage: python scripts/multi_lane_test.py [W H NF]; ALGO=tvl1|farn|brox; LANES="1,2,3"; prints one line per lane count."""
+Usage: python scripts/multi_lane_probe.py [W H NF]; ALGO=tvl1|farn|brox; LANES="1,2,3"; prints one line per lane count."""
 import os
 import sys
 import threading

@@ -57,4 +57,44 @@ def test_single_process_stub_line():
                         "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=120, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert out["n_gpus"] == 1 and out["metric"].startswith("STUB") and "pcie_inclusive" not in out
+    assert out["n_gpus"] == 1 and out["metric"].startswith("STUB") and "pcie_inclusive" not in out["config"]
+
+
+def _self_launched(world, extra):
+    """`python3 bench.py --gpus N ...` with NO launcher around it and no WORLD_SIZE in the environment — the way the
+    driver invokes the bench (BENCH_r02.cmd).  bench.py must start its own N ranks (it used to run ONE rank
+    and print "n_gpus": 1, which would have voided a driver SCALE run)."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env["DFX_BENCH_STUB"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--frames", "41", "--width", "64", "--height", "48", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_self_launch_weak(world):
+    out = _self_launched(world, [])
+    assert out["n_gpus"] == world and out["scaling"] == "weak" and out["data"] == "stub"
+    assert out["config"]["pairs_per_step"] == world * 40
+
+
+def test_self_launch_strong_splits_one_clip():
+    out = _self_launched(2, ["--split", "clip", "--step", "-2"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["pairs_per_step"] == 41 - 2
+    assert "ONE clip split into 2" in out["config"]["workload"]
+
+
+def test_self_launch_propagates_a_failing_rank():
+    """A rank that dies must end the whole command with a non-zero status (not hang the others in the barrier)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DFX_BENCH_STUB"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--frames", "9", "--split", "clip", "--step", "0", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=120, cwd=ROOT)
+    assert r.returncode != 0  # shard_pairs rejects step 0 on every rank

@@ -44,3 +44,19 @@ def test_two_ranks_weak_and_strong_lines():
     assert strong["n_gpus"] == 2 and strong["scaling"] == "strong"
     assert strong["config"]["pairs_per_step"] == 21 - 2
     assert strong["roofline"]["achieved"] > 0
+
+
+def test_self_launched_two_ranks():
+    """`python3 bench.py --gpus 2` as the driver types it (no launcher, no WORLD_SIZE): bench.py starts its own ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DFX_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames",
+           "21", "--width", "320", "--height", "240", "--no-cpu-baseline", "--no-pcie"]
+    for extra, scaling, pairs in (([], "weak", 40), (["--split", "clip"], "strong", 20)):
+        r = subprocess.run(cmd + extra, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["pairs_per_step"] == pairs
+        assert out["value"] > 0 and out["data"] == "synthetic"
