@@ -40,7 +40,7 @@ class BroxEngine final : public AlgoEngine {
     float *d_frames = nullptr;
     int *d_frame_slots = nullptr, *h_slots_pinned = nullptr;
     int B = 0;
-    int sor_mode = 0; // barrier scheme of the fused SOR (k_brox_sor_fused MODE), fixed when the engine is created
+    int sor_r2 = 0; // 1: the round-2 fused SOR kernel (dfx_params.variant & DFX_VAR_BROX_SOR_R2)
     float *d_planes = nullptr;
     long long plane_stride = 0, slot_stride = 0;
     PairDesc *d_pairs = nullptr, *h_pairs_pinned = nullptr;
@@ -64,9 +64,9 @@ void BroxEngine::destroy() {
 
 int BroxEngine::create() {
     const dfx_params &p = c->prm;
-    sor_mode = brox_sor_mode_default();
-    if (const char *e = std::getenv("DFX_BROX_SOR")) // A/B switch of the measurements and the parity tests
-        sor_mode = std::atoi(e);
+    if (p.impl < 0 || p.impl > 1)
+        return dfx_fail(c, DFX_ERR_INVALID, "brox: impl must be 0 (tuned) or 1 (simple)");
+    sor_r2 = (p.variant & DFX_VAR_BROX_SOR_R2) ? 1 : 0;
     if (!(p.brox_scale_factor > 0.f && p.brox_scale_factor < 1.f) || !(p.brox_alpha > 0.f) ||
         p.brox_inner_iterations < 0 || p.brox_outer_iterations < 1 || p.brox_solver_iterations < 0)
         return dfx_fail(c, DFX_ERR_INVALID, "invalid Brox parameters");
@@ -189,10 +189,9 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
                     brox_launch_sor(c->stream, x, uv, ds, 1);
                 }
             } else {
-                const int S = brox_fused_sweeps(p.tvl1_tile_h);
+                const int S = brox_fused_sweeps();
                 for (int si = 0; si < p.brox_solver_iterations; si += S) {
-                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si), p.tvl1_tile_h,
-                                          sor_mode);
+                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si), sor_r2);
                     ds ^= 1; // it wrote the other set
                 }
             }
@@ -200,7 +199,7 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
         brox_launch_add_increment(c->stream, x, uv, ds);
         batch_launches += 2 + (uint64_t)p.brox_inner_iterations *
                                   (1 + (p.impl == 1 ? 1 + 2 * p.brox_solver_iterations
-                                                    : (p.brox_solver_iterations + brox_fused_sweeps(p.tvl1_tile_h) - 1) / brox_fused_sweeps(p.tvl1_tile_h)));
+                                                    : (p.brox_solver_iterations + brox_fused_sweeps() - 1) / brox_fused_sweeps()));
         if (l > 0) {
             brox_launch_prolongate(c->stream, x, uv, lv[l - 1].w, lv[l - 1].h, lv[l - 1].pitch, p.brox_scale_factor,
                                    1.0f / p.brox_scale_factor);

@@ -43,11 +43,10 @@ void brox_launch_level_init(hipStream_t s, const BroxLevelCtx &c, int uv_set, in
 void brox_launch_stage1(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set);
 void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c);
 void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set, int color); // in place
-// n_sweeps (<= brox_fused_sweeps()) full red+black sweeps in one launch (LDS tile, recomputed halo)
-void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps,
-                           int tile_w, int sor_mode); // tile_w: 64 or 128; writes set d_src^1; sor_mode: barrier scheme
-int brox_sor_mode_default(); // k_brox_sor_fused MODE used unless the A/B switch DFX_BROX_SOR says otherwise
-int brox_fused_sweeps(int cfg);
+// n_sweeps (<= brox_fused_sweeps()) full red+black sweeps in one launch (64 x 64 LDS tile, recomputed halo); writes
+// set d_src ^ 1.  r2 != 0: the round-2 kernel (cross-check / A-B), otherwise the packed round-3 kernel.
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int r2);
+int brox_fused_sweeps();
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set);
 // (u,v)[uv_set ^ 1] at the finer geometry = bicubic(u,v[uv_set]) * mul
 void brox_launch_prolongate(hipStream_t s, const BroxLevelCtx &c_coarse, int uv_set, int dw, int dh, int dpitch,

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "brox_kernels.h"
+#include "tvl1_math_pk.h" // f2, pk_fma, the exact Newton division (shared with the TVL1 kernels)
 
 #define BROX_EPS2 1e-6f
 
@@ -413,6 +414,172 @@ __global__ __launch_bounds__(BROX_TW *BROX_TH / 4) void k_brox_sor_fused(BroxLev
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The fused SOR, round 3 (the tuned default).  Same tile (64 x 64, one thread per 2x2 patch, 2*S-pixel recomputed halo,
+// S sweeps per launch), same per-pixel expression in the same order — bit-identical to k_brox_sor and to the round-2
+// kernel above — but built for the two things the round-2 counters showed (VALU busy 33 %, 63 % of wave cycles waiting,
+// one 1024-thread workgroup per CU: profiles/round2/brox/):
+//   * LOAD PHASE.  The round-2 kernel fetched each of its 15 per-pixel inputs with a dword load whose lanes are 8 bytes
+//     apart (x = 2 * lane + k): 60 load instructions per thread, each using half of the bytes the texture-address unit
+//     walks.  Here a patch row is one 8-byte load per plane (x0, lx0 are even and the pitch is a multiple of 64, so the
+//     pair is 8-byte aligned): 29 load instructions, every byte used.  gr = GX(x+1) and gu = GY(y+1) of the patch's
+//     inner edges are the neighbour's gl / gd, already in registers.
+//   * SWEEPS.  The two pixels a thread updates in a half sweep (one colour = one diagonal of the patch) are independent:
+//     the 14 per-pixel values are held as float2 {diagonal element 0, element 1} per colour and the 34 float operations
+//     of an update run once as v_pk_* for both pixels (IEEE per half, nothing contracted: same bits).
+//   * the two reciprocals of stage 2 use the exact Newton sequence of tvl1_math.h (checked element-wise on the GPU
+//     against IEEE division over the Brox range of denominators, tests/test_device_math_gpu.py) on both pixels at once.
+typedef float f2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int S>
+__global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set, int d_src, int n_sweeps, int tiles_x) {
+    constexpr int TW = 64, TH = 64, HALO = 2 * S;
+    __shared__ float WU[TH][TW];
+    __shared__ float WV[TH][TW];
+    const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
+    const int tile = dfx_block_linear(); // neighbouring tiles re-read each other's 2*S-pixel halo: keep them in one L2
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int x0 = tx * (TW - 2 * HALO) - HALO; // even
+    const int y0 = ty * (TH - 2 * HALO) - HALO; // even
+    const int pcol = threadIdx.x & 31, prow = threadIdx.x >> 5;
+    const int lx0 = 2 * pcol, ly0 = 2 * prow;
+    const int x = x0 + lx0, y = y0 + ly0; // pixel (row 0, column 0) of the patch
+
+    const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
+    const float *DU = bplane(c, b, du_plane(d_src)), *DV = bplane(c, b, dv_plane(d_src));
+    float *DUo = bplane(c, b, du_plane(d_src ^ 1)), *DVo = bplane(c, b, dv_plane(d_src ^ 1));
+    const float *GX = bplane(c, b, BROX_PL_GX), *GY = bplane(c, b, BROX_PL_GY);
+    const float *IDU = bplane(c, b, BROX_PL_IDU), *IDV = bplane(c, b, BROX_PL_IDV);
+    const float *NDUDV = bplane(c, b, BROX_PL_NDUDV), *NU = bplane(c, b, BROX_PL_NU), *NV = bplane(c, b, BROX_PL_NV);
+
+    // ---- load phase: rows i = 0, 1 of the patch as float2 (k = 0, 1), masked to 0 outside the image
+    const bool inx0 = x >= 0 && x < w, inx1 = x + 1 >= 0 && x + 1 < w; // x is even: x < 0 puts both columns outside
+    const bool iny[3] = {y >= 0 && y < h, y + 1 >= 0 && y + 1 < h, y + 2 >= 0 && y + 2 < h};
+    long long o[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o[i] = (inx0 && iny[i]) ? ((long long)(y + i) * pitch + x) : 0; // masked rows read element 0
+    auto ld2 = [](const float *P, long long off) -> f2 { return *reinterpret_cast<const f2_a8 *>(P + off); };
+    auto mask = [&](f2 r, int i) -> f2 { return pk_set(inx0 && iny[i] ? r.x : 0.0f, inx1 && iny[i] ? r.y : 0.0f); };
+    f2 r_gl[2], r_gd[2], r_idu[2], r_idv[2], r_nd[2], r_nu[2], r_nv[2], r_u[2], r_v[2], r_du[2], r_dv[2];
+    float gxr[2]; // GX at x + 2: the right neighbour's diffusivity of column 1
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        r_gl[i] = ld2(GX, o[i]);
+        r_gd[i] = ld2(GY, o[i]);
+        r_idu[i] = ld2(IDU, o[i]);
+        r_idv[i] = ld2(IDV, o[i]);
+        r_nd[i] = ld2(NDUDV, o[i]);
+        r_nu[i] = ld2(NU, o[i]);
+        r_nv[i] = ld2(NV, o[i]);
+        r_u[i] = ld2(u, o[i]);
+        r_v[i] = ld2(v, o[i]);
+        r_du[i] = ld2(DU, o[i]);
+        r_dv[i] = ld2(DV, o[i]);
+        gxr[i] = GX[(x + 2 < w) ? o[i] + 2 : o[i]];
+    }
+    const f2 r_gy2 = ld2(GY, o[2]);
+    f2 r_gr[2], r_gu[2], r_gs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        r_gl[i] = mask(r_gl[i], i);
+        r_gd[i] = mask(r_gd[i], i);
+        r_nd[i] = mask(r_nd[i], i);
+        r_nu[i] = mask(r_nu[i], i);
+        r_nv[i] = mask(r_nv[i], i);
+        r_u[i] = mask(r_u[i], i);
+        r_v[i] = mask(r_v[i], i);
+        r_du[i] = mask(r_du[i], i);
+        r_dv[i] = mask(r_dv[i], i);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        // gr = (in && x + 1 < w) ? GX[o + 1] : 0.  Column 0: GX[o + 1] is column 1's own (masked) gl.
+        r_gr[i] = pk_set(inx0 && iny[i] ? r_gl[i].y : 0.0f, (inx1 && iny[i] && x + 2 < w) ? gxr[i] : 0.0f);
+        // gu = (in && y + 1 < h) ? GY[o + pitch] : 0.  Row 0: the (masked) gd of row 1; row 1: row 2 of GY.
+        if (i == 0)
+            r_gu[i] = pk_set(inx0 && iny[0] ? r_gd[1].x : 0.0f, inx1 && iny[0] ? r_gd[1].y : 0.0f);
+        else
+            r_gu[i] = pk_set(inx0 && iny[1] && iny[2] ? r_gy2.x : 0.0f, inx1 && iny[1] && iny[2] ? r_gy2.y : 0.0f);
+        r_gs[i] = ((r_gl[i] + r_gr[i]) + r_gd[i]) + r_gu[i];
+        // stage 2 of the definition, 1 / (data term + sum of diffusivities): the exact division, two pixels at once
+        const f2 den_u = r_idu[i] + r_gs[i], den_v = r_idv[i] + r_gs[i];
+        r_idu[i] = mask(pk_div_with_rcp((f2)(1.0f), den_u, pk_refined_rcp(den_u)), i);
+        r_idv[i] = mask(pk_div_with_rcp((f2)(1.0f), den_v, pk_refined_rcp(den_v)), i);
+        const f2 wu = r_u[i] + r_du[i], wv = r_v[i] + r_dv[i];
+        *reinterpret_cast<f2_a8 *>(&WU[ly0 + i][lx0]) = wu;
+        *reinterpret_cast<f2_a8 *>(&WV[ly0 + i][lx0]) = wv;
+    }
+    // colour pairs: pair q = {element 0: (row 0, column q), element 1: (row 1, column 1 - q)}; (x + y) parity of a patch
+    // element (i, k) is (i + k) & 1 because x0, y0, lx0, ly0 are even, so pair q is what half sweep `q` updates
+#define BROX_PAIR(r) {pk_set(r[0].x, r[1].y), pk_set(r[0].y, r[1].x)}
+    const f2 gl[2] = BROX_PAIR(r_gl), gr[2] = BROX_PAIR(r_gr), gd[2] = BROX_PAIR(r_gd), gu[2] = BROX_PAIR(r_gu);
+    const f2 gs[2] = BROX_PAIR(r_gs), idu[2] = BROX_PAIR(r_idu), idv[2] = BROX_PAIR(r_idv), nd[2] = BROX_PAIR(r_nd);
+    const f2 nu[2] = BROX_PAIR(r_nu), nv[2] = BROX_PAIR(r_nv), uu[2] = BROX_PAIR(r_u), vv[2] = BROX_PAIR(r_v);
+    f2 du[2] = BROX_PAIR(r_du), dv[2] = BROX_PAIR(r_dv);
+#undef BROX_PAIR
+    __syncthreads();
+
+    // neighbour coordinates, clamped at the tile edge exactly like max(lx - 1, 0) / min(lx + 1, TW - 1) of the definition's
+    // tile form (a clamped read returns the pixel's own entry; such pixels are halo and their values are discarded)
+    const int xm = max(lx0 - 1, 0), xp = min(lx0 + 2, TW - 1), ym = max(ly0 - 1, 0), yp = min(ly0 + 2, TH - 1);
+    const float omega = c.omega, om1 = 1.0f - omega;
+    constexpr int ROWS_PER_WAVE = 4;                         // 32 patch columns x 2 patch rows per wavefront
+    const int band0 = (ly0 / ROWS_PER_WAVE) * ROWS_PER_WAVE; // first tile row of this wavefront
+    for (int sw = 0; sw < n_sweeps; ++sw) {
+        // a wavefront whose rows can no longer influence the owned region skips its updates: after sweep s of n the
+        // result is needed on the owned rows +- (2 (n - 1 - s) + 1)
+        const int m = 2 * (n_sweeps - 1 - sw) + 1;
+        const bool live = band0 + ROWS_PER_WAVE - 1 >= HALO - m && band0 < TH - HALO + m;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (live) {
+                // element 0 = (ly0, lx0 + q), element 1 = (ly0 + 1, lx0 + 1 - q)
+                const int ax = lx0 + q, bx = lx0 + 1 - q;
+                const int axl = q ? lx0 : xm, axr = q ? xp : lx0 + 1; // left / right neighbour columns of element 0
+                const int bxl = q ? xm : lx0, bxr = q ? lx0 + 1 : xp; // ... of element 1
+                const f2 Lu = pk_set(WU[ly0][axl], WU[ly0 + 1][bxl]), Ru = pk_set(WU[ly0][axr], WU[ly0 + 1][bxr]);
+                const f2 Du = pk_set(WU[ym][ax], WU[ly0][bx]), Uu = pk_set(WU[ly0 + 1][ax], WU[yp][bx]);
+                const f2 Lv = pk_set(WV[ly0][axl], WV[ly0 + 1][bxl]), Rv = pk_set(WV[ly0][axr], WV[ly0 + 1][bxr]);
+                const f2 Dv = pk_set(WV[ym][ax], WV[ly0][bx]), Uv = pk_set(WV[ly0 + 1][ax], WV[yp][bx]);
+                const f2 su = (((gl[q] * Lu + gr[q] * Ru) + gd[q] * Du) + gu[q] * Uu) - gs[q] * uu[q];
+                const f2 sv = (((gl[q] * Lv + gr[q] * Rv) + gd[q] * Dv) + gu[q] * Uv) - gs[q] * vv[q];
+                const f2 du_n = om1 * du[q] + omega * (idu[q] * ((su - nu[q]) - nd[q] * dv[q]));
+                const f2 dv_n = om1 * dv[q] + omega * (idv[q] * ((sv - nv[q]) - nd[q] * du_n));
+                du[q] = du_n;
+                dv[q] = dv_n;
+                // publish right away: this half sweep reads w only at pixels of the other colour (or, clamped, at the
+                // pixel's own entry) and each entry of this colour is written by the one thread that owns it
+                const f2 wu = uu[q] + du_n, wv = vv[q] + dv_n;
+                WU[ly0][ax] = wu.x;
+                WU[ly0 + 1][bx] = wu.y;
+                WV[ly0][ax] = wv.x;
+                WV[ly0 + 1][bx] = wv.y;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- store the owned region into the other du / dv set
+    if (lx0 >= HALO && lx0 < TW - HALO && x < w) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ly = ly0 + i, yy = y + i;
+            if (ly >= HALO && ly < TH - HALO && yy < h) {
+                const long long oo = (long long)yy * pitch + x;
+                const f2 a = i == 0 ? pk_set(du[0].x, du[1].x) : pk_set(du[1].y, du[0].y);
+                const f2 bq = i == 0 ? pk_set(dv[0].x, dv[1].x) : pk_set(dv[1].y, dv[0].y);
+                if (x + 1 < w) {
+                    *reinterpret_cast<f2_a8 *>(DUo + oo) = a;
+                    *reinterpret_cast<f2_a8 *>(DVo + oo) = bq;
+                } else {
+                    DUo[oo] = a.x;
+                    DVo[oo] = bq.x;
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int uv_set, int d_set) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -497,53 +664,19 @@ void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c) {
 void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set, int color) {
     hipLaunchKernelGGL(k_brox_sor, bgrid((c.w + 1) / 2, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set, color);
 }
-// cfg (dfx_params.tvl1_tile_h doubles as the knob): 0 / 645 = 64x64 tile, 5 sweeps per launch (default: the
-// reference's 10 solver iterations are two launches; measured 164 pairs/s at 1080p against 138 for 64x32 / 2 sweeps and
-// 133 for 128x32 / 2); 64 = 64x32, 2 sweeps; 128 = 128x32, 2; 642 / 643 = 64x64 with 2 / 3.
-static void sor_cfg(int cfg, int &tw, int &th, int &S) {
-    tw = 64, th = 64, S = 5;
-    if (cfg == 128)
-        tw = 128, th = 32, S = 2;
-    else if (cfg == 64)
-        th = 32, S = 2;
-    else if (cfg == 642 || cfg == 643)
-        S = cfg - 640;
-}
-#ifndef BROX_SOR_MODE_DEFAULT
-#define BROX_SOR_MODE_DEFAULT 2
-#endif
-template <int TW, int TH, int S, int MODE = 0>
-static void sor_launch(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps) {
+// 64 x 64 tile, 5 sweeps per launch: the reference's 10 solver iterations are two launches (measured: 64x64x5 192
+// pairs/s at 1080p against 153 / 141 for 3 / 2 sweeps and 145 for 64x32 and 128x32 tiles).
+constexpr int BROX_SWEEPS = 5;
+int brox_fused_sweeps() { return BROX_SWEEPS; }
+// r2 = the round-2 kernel (dfx_params.variant & DFX_VAR_BROX_SOR_R2), otherwise k_brox_sor_pk
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int r2) {
+    constexpr int TW = 64, TH = 64, S = BROX_SWEEPS;
     const int tiles_x = (c.w + (TW - 4 * S) - 1) / (TW - 4 * S), tiles_y = (c.h + (TH - 4 * S) - 1) / (TH - 4 * S);
-    hipLaunchKernelGGL((k_brox_sor_fused<TW, TH, S, MODE>), dim3(tiles_x * tiles_y, 1, c.n_pairs), dim3(TW * TH / 4), 0,
-                       s, c, uv_set, d_src, n_sweeps, tiles_x);
-}
-int brox_sor_mode_default() { return BROX_SOR_MODE_DEFAULT; }
-// mode: barrier scheme of the default tile (k_brox_sor_fused MODE); the engine reads the A/B switch DFX_BROX_SOR once
-// when it is created
-void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int cfg,
-                           int mode) {
-    int tw, th, S;
-    sor_cfg(cfg, tw, th, S);
-    if (tw == 128)
-        sor_launch<128, 32, 2>(s, c, uv_set, d_src, n_sweeps);
-    else if (th == 32)
-        sor_launch<64, 32, 2>(s, c, uv_set, d_src, n_sweeps);
-    else if (S == 2)
-        sor_launch<64, 64, 2>(s, c, uv_set, d_src, n_sweeps);
-    else if (S == 3)
-        sor_launch<64, 64, 3>(s, c, uv_set, d_src, n_sweeps);
-    else if (mode == 1)
-        sor_launch<64, 64, 5, 1>(s, c, uv_set, d_src, n_sweeps);
-    else if (mode == 2)
-        sor_launch<64, 64, 5, 2>(s, c, uv_set, d_src, n_sweeps);
+    const dim3 grid(tiles_x * tiles_y, 1, c.n_pairs), block(TW * TH / 4);
+    if (r2)
+        hipLaunchKernelGGL((k_brox_sor_fused<TW, TH, S, 2>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
     else
-        sor_launch<64, 64, 5>(s, c, uv_set, d_src, n_sweeps);
-}
-int brox_fused_sweeps(int cfg) {
-    int tw, th, S;
-    sor_cfg(cfg, tw, th, S);
-    return S;
+        hipLaunchKernelGGL((k_brox_sor_pk<S>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
 }
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set) {
     hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set);

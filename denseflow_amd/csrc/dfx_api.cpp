@@ -51,29 +51,49 @@ void default_params(dfx_params *p) {
 
 } // namespace
 
-int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity) {
+int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity, bool report) {
+    auto matches = [&](const dfx_context::Tail &t) {
+        return (up_to == 0 || t.ticket <= up_to) && (parity < 0 || t.parity == parity);
+    };
+    std::vector<std::unique_ptr<dfx_context::Tail>> finished;
     int rc = DFX_OK;
-    for (;;) {
-        std::unique_ptr<dfx_context::Tail> t;
-        {
-            std::lock_guard<std::mutex> lock(c->tails_mtx);
-            for (auto it = c->tails.begin(); it != c->tails.end(); ++it) {
-                if ((up_to == 0 || (*it)->ticket <= up_to) && (parity < 0 || (*it)->parity == parity)) {
-                    t = std::move(*it);
-                    c->tails.erase(it);
-                    break;
+    {
+        std::unique_lock<std::mutex> lock(c->tails_mtx);
+        // a tail is visible to every caller until its worker is done: nobody can mistake "being joined" for "finished"
+        c->tails_cv.wait(lock, [&] {
+            for (const auto &t : c->tails)
+                if (matches(*t) && !t->done)
+                    return false;
+            return true;
+        });
+        for (auto it = c->tails.begin(); it != c->tails.end();) {
+            if (matches(**it)) {
+                if ((*it)->rc != DFX_OK)
+                    c->tail_errors.push_back({(*it)->ticket, (*it)->rc, (*it)->err});
+                finished.push_back(std::move(*it));
+                it = c->tails.erase(it);
+            } else {
+                ++it;
+            }
+        }
+        if (report) {
+            for (auto it = c->tail_errors.begin(); it != c->tail_errors.end();) {
+                if (up_to == 0 || it->ticket <= up_to) {
+                    if (rc == DFX_OK) {
+                        rc = it->rc;
+                        c->set_err(it->err);
+                    }
+                    it = c->tail_errors.erase(it);
+                } else {
+                    ++it;
                 }
             }
         }
-        if (!t)
-            return rc;
-        if (t->worker.joinable()) // joined outside the lock: the submitting thread may be queueing the next tail
-            t->worker.join();
-        if (t->rc != DFX_OK && rc == DFX_OK) {
-            rc = t->rc;
-            c->err = t->err;
-        }
     }
+    for (auto &t : finished) // done was the worker's last action: these joins return at once
+        if (t->worker.joinable())
+            t->worker.join();
+    return rc;
 }
 
 namespace {
@@ -486,25 +506,34 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             }
             const bool quant = out.quantized;
             const size_t dpitch = quant ? out.img_pitch : out.out_pitch;
+            std::mutex *mtx = &c->tails_mtx;
+            std::condition_variable *cv = &c->tails_cv;
             t->worker = std::thread([=]() {
                 (void)hipSetDevice(dev);
                 const hipError_t e = hipEventSynchronize(ev);
+                int wrc = DFX_OK;
+                std::string werr;
                 if (e != hipSuccess) {
-                    tp->rc = DFX_ERR_HIP;
-                    tp->err = std::string("deferred download failed: ") + hipGetErrorString(e);
-                    return;
-                }
-                if (!hb)
-                    return;
-                const size_t pl = (size_t)W * H;
-                for (int j = 0; j < lp.nb; ++j) {
-                    if (quant) {
-                        copy_rows(dst_a[j], dpitch, hb + (size_t)j * pl, (size_t)W, H);
-                        copy_rows(dst_b[j], dpitch, hb + ((size_t)lp.nb + j) * pl, (size_t)W, H);
-                    } else {
-                        copy_rows(dst_a[j], dpitch, hb + (size_t)j * pl * 8, (size_t)W * 8, H);
+                    wrc = DFX_ERR_HIP;
+                    werr = std::string("deferred download failed: ") + hipGetErrorString(e);
+                } else if (hb) {
+                    const size_t pl = (size_t)W * H;
+                    for (int j = 0; j < lp.nb; ++j) {
+                        if (quant) {
+                            copy_rows(dst_a[j], dpitch, hb + (size_t)j * pl, (size_t)W, H);
+                            copy_rows(dst_b[j], dpitch, hb + ((size_t)lp.nb + j) * pl, (size_t)W, H);
+                        } else {
+                            copy_rows(dst_a[j], dpitch, hb + (size_t)j * pl * 8, (size_t)W * 8, H);
+                        }
                     }
                 }
+                {   // last action: publish the result; the context outlives every tail (dfx_destroy drains them)
+                    std::lock_guard<std::mutex> lock(*mtx);
+                    tp->rc = wrc;
+                    tp->err = werr;
+                    tp->done = true;
+                }
+                cv->notify_all();
             });
             *ticket = t->ticket;
             {
@@ -530,12 +559,12 @@ int calc_batch_impl(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                     unsigned long long *ticket = nullptr) {
     const int rc = calc_batch_body(c, frames, frame_pitch, d_frames, d_pitch, d_frame_stride, n_frames, step, out, ticket);
     if (rc != DFX_OK) {
-        const std::string keep = c->err;
+        const std::string keep = c->get_err();
         (void)hipStreamSynchronize(c->copy_stream);
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamSynchronize(c->d2h_stream);
         (void)dfx_finish_tails(c, 0, -1);
-        c->err = keep;
+        c->set_err(keep);
     }
     return rc;
 }
@@ -641,7 +670,7 @@ int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height
     };
     const int rc = init();
     if (rc != DFX_OK) {
-        g_create_error = c->err;
+        g_create_error = c->get_err();
         dfx_destroy(c);
         return rc;
     }
@@ -773,7 +802,7 @@ int dfx_submit_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame
 int dfx_wait(dfx_handle h, uint64_t ticket) {
     if (!h)
         return DFX_ERR_INVALID;
-    return dfx_finish_tails(h, ticket, -1);
+    return dfx_finish_tails(h, ticket, -1, /*report=*/true);
 }
 
 int dfx_calc_batch_u8_device(dfx_handle h, const uint8_t *d_frames, size_t pitch, size_t frame_stride, int n_frames,
@@ -925,7 +954,13 @@ void dfx_reset_stats(dfx_handle h) {
         std::memset(&h->stats, 0, sizeof h->stats);
 }
 
-const char *dfx_last_error(dfx_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+const char *dfx_last_error(dfx_handle h) {
+    if (!h)
+        return g_create_error.c_str();
+    thread_local std::string text; // a copy per calling thread: the collector and the owner may both ask
+    text = h->get_err();
+    return text.c_str();
+}
 
 void dfx_destroy(dfx_handle h) {
     if (!h)

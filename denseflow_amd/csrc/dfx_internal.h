@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <deque>
 #include <memory>
@@ -42,7 +43,18 @@ struct dfx_context {
     dfx_algo algo = DFX_ALGO_TVL1;
     int W = 0, H = 0;
     dfx_params prm{};
-    std::string err;
+    // Last error text.  dfx_wait may run on a collector thread beside the owner's dfx_submit_*, and both may fail:
+    // every access goes through set_err / get_err.
+    std::string err_;
+    mutable std::mutex err_mtx;
+    void set_err(const std::string &m) {
+        std::lock_guard<std::mutex> lock(err_mtx);
+        err_ = m;
+    }
+    std::string get_err() const {
+        std::lock_guard<std::mutex> lock(err_mtx);
+        return err_;
+    }
     // format of the frames handed to the calc entry points (dfx_set_source_format); 0 = the handle's own W x H gray
     int src_w = 0, src_h = 0, src_ch = 1;
     bool prepares() const { return src_w > 0; }
@@ -83,21 +95,33 @@ struct dfx_context {
     unsigned long long batch_seq = 0;
     // Deferred tails of dfx_submit_*: the last download of a FlowBuffer (and, for small frames, the hand-over from
     // the bounce buffer to the caller's buffers) completes on a helper thread while the next FlowBuffer is issued.
+    // A tail stays registered in `tails` until its worker has FINISHED (done, set under tails_mtx): whoever asks about
+    // a ticket or a staging parity — the collector's dfx_wait, the submitting thread's bounce-buffer guard, a
+    // re-allocation — sees it and blocks on tails_cv until then.  Only finished tails are removed and joined.
     struct Tail {
         unsigned long long ticket = 0;
         int parity = 0;
         int rc = DFX_OK;
         std::string err;
+        bool done = false;
         std::thread worker;
     };
+    struct TailError { // a failed tail's status is kept until a dfx_wait that covers its ticket has reported it
+        unsigned long long ticket;
+        int rc;
+        std::string err;
+    };
     std::deque<std::unique_ptr<Tail>> tails;
+    std::vector<TailError> tail_errors;
     std::mutex tails_mtx; // dfx_wait may be called from another thread than the one that submits
+    std::condition_variable tails_cv;
     unsigned long long next_ticket = 1;
 };
 
-// Join the deferred tails with ticket <= up_to (0 = all) / of staging parity `parity` (-1 = any).  Returns the first
-// error a tail met.
-int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity);
+// Wait until the deferred tails with ticket <= up_to (0 = all) / of staging parity `parity` (-1 = any) have finished.
+// report = true (dfx_wait): returns, and forgets, the first error of a tail with ticket <= up_to; report = false
+// (housekeeping inside other entry points): errors stay recorded for the dfx_wait of their ticket.
+int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity, bool report = false);
 
 #define HIPCHK(ctx, call)                                                                                       \
     do {                                                                                                        \
@@ -106,14 +130,14 @@ int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity);
             char buf_[512];                                                                                     \
             snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,        \
                      __LINE__);                                                                                 \
-            (ctx)->err = buf_;                                                                                  \
+            (ctx)->set_err(buf_);                                                                                 \
             return DFX_ERR_HIP;                                                                                 \
         }                                                                                                       \
     } while (0)
 
 inline int dfx_fail(dfx_context *c, int code, const std::string &msg) {
     if (c)
-        c->err = msg;
+        c->set_err(msg);
     return code;
 }
 

@@ -167,12 +167,11 @@ void FarnebackEngine::destroy() {
 
 int FarnebackEngine::create() {
     const dfx_params &p = c->prm;
-    skip_zero_weights = farn_skip_zero_weights_default();
-    polyexp_rows = farn_polyexp_rows_default();
-    if (const char *e = std::getenv("DFX_FARN_SKIP0")) // A/B switches of the measurements and the parity tests
-        skip_zero_weights = std::atoi(e);
-    if (const char *e = std::getenv("DFX_FARN_POLYROWS"))
-        polyexp_rows = std::atoi(e);
+    if (p.impl < 0 || p.impl > 1)
+        return dfx_fail(c, DFX_ERR_INVALID, "farn: impl must be 0 (tuned) or 1 (simple)");
+    // cross-check forms of the frame preparation (dfx_params.variant; same bits both ways)
+    skip_zero_weights = (p.variant & DFX_VAR_FARN_EVAL_ZERO_TAPS) ? 0 : farn_skip_zero_weights_default();
+    polyexp_rows = (p.variant & DFX_VAR_FARN_POLY_ONE_ROW) ? 0 : farn_polyexp_rows_default();
     if (p.farn_poly_n != 5)
         return dfx_fail(c, DFX_ERR_UNSUPPORTED, "Farneback: only polyN = 5 (the reference's default) is built");
     if (p.farn_flags != 0)

@@ -133,22 +133,22 @@ DFX_HD void tvl1_end_segment(Tvl1State &s, const Tvl1LoopCfg &c, const Tvl1StepP
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tile geometry of one step of the default step kernel (k_tvl1_step_fused, 64 x TH tiles).
-//   geom bit 1: the halo is as wide as the step is long (a segment-final step of n < K iterations gets an n-pixel
-//               halo and owns (64-2n) x (TH-2n) pixels per tile);
-//   geom bit 0: tile columns start at x = 0 instead of -halo: the first tile also owns its left halo columns (the
-//               image border needs no halo) and the last one everything up to the right border.
+// Tile geometry of a step of the default step kernel (k_tvl1_step_fused, 64 x 32 tiles with a K-pixel halo).
+//   shift = 1 (default): tile columns start at x = 0 instead of -K: the first tile also owns its left halo columns (the
+//               image border needs no halo) and the last one everything up to the right border — ceil((w - 2K) /
+//               (64 - 2K)) tile columns instead of ceil(w / (64 - 2K)): 14 instead of 15 at the coarsest 1080p level;
+//   shift = 0: the classic tiling (kept as a cross-check: dfx_params.variant & DFX_VAR_TVL1_CLASSIC_GEOM).
 // The kernel, the launcher (grid size) and the CPU test of the ownership partition all use these functions.
 struct Tvl1StepGeom {
-    int halo;     // Kh
-    int ntx, nty; // tiles of this step
-    int shift;    // geom bit 0
+    int halo;     // K
+    int ntx, nty; // tiles of a step
+    int shift;
 };
 
-DFX_HD Tvl1StepGeom tvl1_step_geom(int w, int h, int tw, int th, int K, int n_iters, int geom) {
+DFX_HD Tvl1StepGeom tvl1_step_geom(int w, int h, int tw, int th, int K, int shift) {
     Tvl1StepGeom g;
-    g.halo = (geom & 2) ? (n_iters < K ? n_iters : K) : K;
-    g.shift = geom & 1;
+    g.halo = K;
+    g.shift = shift ? 1 : 0;
     const int sw = tw - 2 * g.halo, sh = th - 2 * g.halo;
     if (g.shift) {
         const int n = (w - 2 * g.halo + sw - 1) / sw;
@@ -183,10 +183,9 @@ DFX_HD bool tvl1_tile_owns(const Tvl1StepGeom &g, const Tvl1TilePlace &p, int tw
            gx >= 0 && gx < w && gy >= 0 && gy < h;
 }
 
-// Workgroups per pair the launcher has to provide: the tile count of a full K-iteration step (shorter steps never
-// have more tiles).  With an in-kernel warp phase (classic tiling) the classic count is needed.
-DFX_HD int tvl1_step_grid(int w, int h, int tw, int th, int K, int geom, int split_warp) {
-    const Tvl1StepGeom full = tvl1_step_geom(w, h, tw, th, K, K, split_warp ? geom : (geom & ~1));
-    return full.ntx * full.nty;
+// Workgroups per pair of a step launch = tiles of the step.  With an in-kernel warp phase (which tiles the image the
+// classic way) the classic count is needed.
+DFX_HD int tvl1_step_grid(int w, int h, int tw, int th, int K, int shift, int split_warp) {
+    const Tvl1StepGeom g = tvl1_step_geom(w, h, tw, th, K, split_warp ? shift : 0);
+    return g.ntx * g.nty;
 }
-

@@ -17,12 +17,6 @@
 #include "dfx_internal.h"
 #include "tvl1_kernels.h"
 
-// Tile geometry of the default step kernel (k_tvl1_step_fused, Tvl1LevelCtx::geom): bit 0 = tile columns start at
-// x = 0, bit 1 = halo as wide as the step is long.
-#ifndef DFX_TVL1_GEOM_DEFAULT
-#define DFX_TVL1_GEOM_DEFAULT 3
-#endif
-
 namespace {
 
 struct Level {
@@ -76,7 +70,7 @@ class Tvl1Engine final : public AlgoEngine {
     int done_token = 0;
     int group_override = 0;
     bool split_warp = false; // backward warp as its own kernel in front of every step (packed step kernels only)
-    int geom = 0;            // step-kernel tile geometry (Tvl1LevelCtx::geom), default tile function only
+    int geom = 0;            // 1 = tile columns of the step kernel start at x = 0 (Tvl1LevelCtx::geom)
     int launched_steps[DFX_LVL_MAX] = {0};
 
     Tvl1LoopCfg loop{};
@@ -118,16 +112,16 @@ int Tvl1Engine::create() {
     if (p.tvl1_nscales < 1 || p.tvl1_nscales > DFX_LVL_MAX || p.tvl1_warps < 0 || p.tvl1_warps > TVL1_MAX_WARPS ||
         p.tvl1_iterations < 0 || !(p.tvl1_scale_step > 0.0 && p.tvl1_scale_step < 1.0) || !(p.tvl1_theta > 0.0))
         return dfx_fail(c, DFX_ERR_INVALID, "invalid TVL1 parameters");
-    if (const char *g = std::getenv("DFX_GROUP"))
-        group_override = std::atoi(g);
-    // the dedicated warp kernel does not write the grad plane: only the packed tile functions (impl 0 / 3) rebuild it
-    split_warp = (p.impl == 0 || p.impl == 3) && p.tvl1_iterations > 0; // zero iterations: warps inside the step kernel
-    if (const char *g = std::getenv("DFX_TVL1_SPLIT_WARP")) // A/B switch for measurements
-        split_warp = split_warp && std::atoi(g) != 0;
-
-    geom = (p.impl == 0 && (p.tvl1_tile_h == 0 || p.tvl1_tile_h == 321)) ? DFX_TVL1_GEOM_DEFAULT : 0;
-    if (const char *g = std::getenv("DFX_TVL1_GEOM")) // A/B switch for measurements and the parity tests
-        geom = (p.impl == 0 && (p.tvl1_tile_h == 0 || p.tvl1_tile_h == 321)) ? (std::atoi(g) & 3) : 0;
+    if (p.impl < 0 || p.impl > 2)
+        return dfx_fail(c, DFX_ERR_INVALID, "tvl1: impl must be 0 (tuned), 1 (simple) or 2 (scalar tile function)");
+    if (p.tvl1_math < 0 || p.tvl1_math > 1 || (p.tvl1_math == 1 && p.impl != 0))
+        return dfx_fail(c, DFX_ERR_INVALID, "tvl1_math must be 0 (exact) or 1 (fast; tuned kernel only)");
+    group_override = std::max(0, std::min(p.step_group, 64));
+    // the dedicated warp kernel does not write the grad plane: only the packed tile function (impl 0) rebuilds it;
+    // zero iterations: warps inside the step kernel
+    split_warp = p.impl == 0 && p.tvl1_iterations > 0 && !(p.variant & DFX_VAR_TVL1_WARP_IN_STEP);
+    // tile columns from x = 0 (tvl1_ctrl.h) need every warp outside the step kernel (its warp phase tiles classically)
+    geom = (p.impl == 0 && split_warp && !(p.variant & DFX_VAR_TVL1_CLASSIC_GEOM)) ? 1 : 0;
 
     // pyramid (A.2 step 3): cvRound(size*scaleStep) per level; a level below 16 px is discarded
     {
@@ -153,7 +147,7 @@ int Tvl1Engine::create() {
     if (p.impl == 1)
         loop.fuse_k = 1;
     else
-        loop.fuse_k = std::max(1, std::min(p.tvl1_fuse_k > 0 ? p.tvl1_fuse_k : 4, tvl1_fused_max_k(p.tvl1_tile_h)));
+        loop.fuse_k = std::max(1, std::min(p.tvl1_fuse_k > 0 ? p.tvl1_fuse_k : 4, tvl1_fused_max_k()));
     kc.l_t = (float)(p.tvl1_lambda * p.tvl1_theta);
     kc.taut = (float)(p.tvl1_tau / p.tvl1_theta);
     kc.theta = (float)p.tvl1_theta;
@@ -289,7 +283,7 @@ int Tvl1Engine::steps_per_group(int s, int nb) const {
 int Tvl1Engine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long long out_stride) {
     std::memcpy(h_pairs_pinned, h_pairs, sizeof(PairDesc) * nb);
     HIPCHK(c, hipMemcpyAsync(d_pairs, h_pairs_pinned, sizeof(PairDesc) * nb, hipMemcpyHostToDevice, c->stream));
-    const int impl = c->prm.impl, tile_h = c->prm.tvl1_tile_h;
+    const int impl = c->prm.impl, math = c->prm.tvl1_math;
     const float up = (float)(1.0 / c->prm.tvl1_scale_step);
     const int hard_limit = loop.warps * (loop.iterations + 2) + 64;
 
@@ -307,7 +301,7 @@ int Tvl1Engine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
                 for (int i = 0; i < G; ++i) {
                     if (split_warp)
                         tvl1_launch_warp(c->stream, x, step_id);
-                    tvl1_launch_step(c->stream, x, step_id++, impl, tile_h);
+                    tvl1_launch_step(c->stream, x, step_id++, impl, math);
                 }
                 c->stats.kernel_launches += (uint64_t)G * (split_warp ? 2 : 1);
                 HIPCHK(c, hipEventRecord(ev_group[g & 1], c->stream));

@@ -16,9 +16,9 @@ void tvl1_launch_centered_gradient(hipStream_t s, const float *frame_I, float *f
                                    int h, int pitch);
 void tvl1_launch_level_begin(hipStream_t s, const Tvl1LevelCtx &c, int first_level);
 void tvl1_launch_warp(hipStream_t s, const Tvl1LevelCtx &c, int step_id); // dedicated backward-warp kernel of a step
-void tvl1_launch_step(hipStream_t s, const Tvl1LevelCtx &c, int step_id, int impl, int tile_h);
-int tvl1_step_blocks(const Tvl1LevelCtx &c, int impl, int tile_h); // workgroups per pair of a step launch
-int tvl1_fused_max_k(int tile_h);                           // largest supported inner-iteration fusion
+void tvl1_launch_step(hipStream_t s, const Tvl1LevelCtx &c, int step_id, int impl, int math);
+int tvl1_step_blocks(const Tvl1LevelCtx &c, int impl); // workgroups per pair of a step launch
+int tvl1_fused_max_k();                                // largest supported inner-iteration fusion
 void tvl1_launch_upsample_u(hipStream_t s, const Tvl1LevelCtx &c_src, int dw, int dh, int dpitch, float ifx, float ify,
                             float up);
 void tvl1_launch_merge(hipStream_t s, const Tvl1LevelCtx &c0, float *out, long long out_stride);

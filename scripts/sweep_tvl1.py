@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Within-process A/B sweep of engine knobs (fuse_k, max_batch, impl) on one resident clip.
-Usage: python scripts/sweep_tvl1.py [W H NF] ; prints one line per configuration."""
+"""Within-process A/B sweep of engine knobs on one resident clip.
+Usage: SWEEP="impl:K:B[:variant[:math]],..." ALGO=tvl1|farn|brox python scripts/sweep_tvl1.py [W H NF]
+(variant = dfx_params.variant, DFX_VAR_* bits; math = dfx_params.tvl1_math); prints one line per configuration and
+whether its flows are bit-identical to the first configuration's."""
 import itertools
 import os
 import sys
@@ -25,21 +27,14 @@ ref = None
 for cfg in configs:
     parts = [int(v) for v in cfg.split(":")]
     impl, k, b = parts[:3]
-    th = parts[3] if len(parts) > 3 else 0
-    if len(parts) > 4:  # step-kernel tile geometry (tvl1) — read by dfx_create
-        os.environ["DFX_TVL1_GEOM"] = str(parts[4])
-    if len(parts) > 5:  # fused-SOR barrier scheme (brox) — read per launch
-        os.environ["DFX_BROX_SOR"] = str(parts[5])
-    if len(parts) > 6:  # zero-weight pyramid taps skipped (farn) — read per launch
-        os.environ["DFX_FARN_SKIP0"] = str(parts[6])
-    if len(parts) > 7:  # rows per workgroup of the polynomial expansion (farn) — read per launch
-        os.environ["DFX_FARN_POLYROWS"] = str(parts[7])
+    variant = parts[3] if len(parts) > 3 else 0
+    math = parts[4] if len(parts) > 4 else 0
     extra = {"tvl1_nscales": int(os.environ["NSCALES"])} if os.environ.get("NSCALES") else {}
     if os.environ.get("ITERS"):
         extra["tvl1_iterations"] = int(os.environ["ITERS"])
     if os.environ.get("EPS"):
         extra["tvl1_epsilon"] = float(os.environ["EPS"])
-    eng = denseflow_amd.FlowEngine(W, H, ALGO, impl=impl, tvl1_fuse_k=k, max_batch=b, tvl1_tile_h=th, **extra)
+    eng = denseflow_amd.FlowEngine(W, H, ALGO, impl=impl, tvl1_fuse_k=k, max_batch=b, variant=variant, tvl1_math=math, **extra)
     run = lambda: eng.calc_optflows_device(d_frames.data_ptr(), W, W * H, NF, 1, d_flows.data_ptr(), W * H * 2)
     run()
     eng.reset_stats()
@@ -53,7 +48,7 @@ for cfg in configs:
     same = "ref" if ref is None else ("bit-identical" if torch.equal(out, ref) else "DIFFERENT max|d|=%g" % float((out - ref).abs().max()))
     if ref is None:
         ref = out
-    print(f"impl={impl} K={k} B={b} TH={th} cfg={cfg}: {reps*(NF-1)/dt:8.1f} pairs/s  dev_ms/pair={st.device_ms/st.pairs:7.3f} step_ms/pair={st.step_ms/st.pairs:7.3f} "
+    print(f"impl={impl} K={k} B={b} variant={variant} math={math}: {reps*(NF-1)/dt:8.1f} pairs/s  dev_ms/pair={st.device_ms/st.pairs:7.3f} step_ms/pair={st.step_ms/st.pairs:7.3f} "
           f"launches/pair={st.kernel_launches/st.pairs:7.1f} noop={st.noop_steps/max(st.step_launches,1):.3f} "
           f"alg_GB/s(step)={st.step_algorithmic_bytes/(st.step_ms*1e-3)/1e9:8.1f}  [{same}]", flush=True)
     if os.environ.get("SWEEP_LEVELS"):

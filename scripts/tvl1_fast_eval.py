@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Exact vs fast TVL1 arithmetic (dfx_params.tvl1_math) over the BASELINE clips, pair by pair, on the GPU.
+
+    python scripts/tvl1_fast_eval.py [out.md]
+
+For every pair: max-abs and mean-abs difference of the fast flow against the exact one (which is the oracle's, bit for
+bit), and whether the executed inner-iteration table differs.  Workloads: all 299 pairs of the 1080p seed-2 clip
+(BASELINE configs[1]), 8 clips of the 224x224 list (seeds 1000..1007, configs[3]), 4 pairs at 3840x2160 (seed 5).
+The acceptance bar is the north star's: max-abs <= 1e-3 px on u/v before bounding."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import denseflow_amd  # noqa: E402
+from denseflow_amd.synth import SynthClip  # noqa: E402
+
+
+def table(st):
+    return [tuple(r[:5]) for r in st.iters_table()[:st.levels]]
+
+
+def run(name, w, h, seeds, n_frames, step=1):
+    rows = []
+    t0 = time.time()
+    with denseflow_amd.FlowEngine(w, h, "tvl1", max_batch=1) as ex, \
+            denseflow_amd.FlowEngine(w, h, "tvl1", max_batch=1, tvl1_math=1) as fa:
+        for seed in seeds:
+            clip = SynthClip(w, h, seed)
+            prev = clip.frame(0)
+            for i in range(n_frames - step):
+                nxt = clip.frame(i + step) if step == 1 else None
+                a, b = (prev, nxt) if step == 1 else (clip.frame(i), clip.frame(i + step))
+                fe = ex.calc(a, b)
+                te = table(ex.stats())
+                ff = fa.calc(a, b)
+                tf = table(fa.stats())
+                d = np.abs(fe - ff)
+                rows.append((float(d.max()), float(d.mean()), te != tf, sum(map(sum, te)), sum(map(sum, tf)),
+                             float(np.abs(fe).max())))
+                if step == 1:
+                    prev = nxt
+    r = np.array([(a, b, c, d, e, f) for a, b, c, d, e, f in rows], dtype=np.float64)
+    return {
+        "name": name, "pairs": len(rows), "max_abs": r[:, 0].max(), "p99_max_abs": float(np.percentile(r[:, 0], 99)),
+        "median_max_abs": float(np.median(r[:, 0])), "mean_abs": r[:, 1].mean(), "tables_differ": int(r[:, 2].sum()),
+        "iters_exact": r[:, 3].mean(), "iters_fast": r[:, 4].mean(), "over_bar": int((r[:, 0] > 1e-3).sum()),
+        "flow_max": r[:, 5].max(), "seconds": time.time() - t0,
+    }
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else None
+    quick = os.environ.get("QUICK") == "1"
+    res = [
+        run("1920x1080, seed 2, 300 frames (BASELINE configs[1])", 1920, 1080, [2], 40 if quick else 300),
+        run("224x224, seeds 1000..1007, 300 frames each (BASELINE configs[3] list)", 224, 224,
+            list(range(1000, 1002 if quick else 1008)), 60 if quick else 300),
+        run("3840x2160, seed 5, 5 frames", 3840, 2160, [5], 3 if quick else 5),
+    ]
+    lines = ["| workload | pairs | max-abs (px) | 99th pct of per-pair max-abs | median | mean-abs | pairs over 1e-3 | "
+             "pairs whose iteration table differs | mean inner iterations exact / fast | largest |flow| |",
+             "|---|---|---|---|---|---|---|---|---|---|"]
+    for r in res:
+        lines.append(f"| {r['name']} | {r['pairs']} | {r['max_abs']:.3g} | {r['p99_max_abs']:.3g} | "
+                     f"{r['median_max_abs']:.3g} | {r['mean_abs']:.3g} | {r['over_bar']} | {r['tables_differ']} | "
+                     f"{r['iters_exact']:.1f} / {r['iters_fast']:.1f} | {r['flow_max']:.2f} |")
+    text = "\n".join(lines)
+    print(text)
+    if out:
+        with open(out, "w") as f:
+            f.write("# TVL1 exact vs fast arithmetic, pair by pair (scripts/tvl1_fast_eval.py)\n\n" + text + "\n")
+
+
+if __name__ == "__main__":
+    main()

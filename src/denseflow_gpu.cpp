@@ -337,10 +337,27 @@ void DenseFlow::collect_flows() {
             p = std::move(pending_q_.front());
             pending_q_.pop();
         }
-        if (p->ticket && p->handle && dfx_wait(p->handle, p->ticket) != DFX_OK)
-            pending_error_ = dfx_last_error(p->handle);
+        bool failed;
+        {
+            unique_lock<mutex> lock(pending_mtx_);
+            failed = !pending_error_.empty();
+        }
+        if (p->ticket && p->handle && dfx_wait(p->handle, p->ticket) != DFX_OK && !failed) {
+            const string msg = dfx_last_error(p->handle);
+            unique_lock<mutex> lock(pending_mtx_);
+            pending_error_ = msg.empty() ? string("dfx_wait failed") : msg;
+            failed = true;
+        }
         const bool fin = p->is_final;
-        flows_queue.push(std::move(p->flows), fin);
+        if (failed) {
+            // The planes of this FlowBuffer (and of every later one) are undefined: nothing of them may reach the save
+            // stage — it would write garbage files and, with is_record, mark the video done.  Closing the queues lets the
+            // other stages wind down on an empty, unmarked final buffer; calc_optflows throws at its next call.
+            frames_gray_queue.close();
+            flows_queue.close();
+        } else {
+            flows_queue.push(std::move(p->flows), fin);
+        }
         {
             unique_lock<mutex> lock(pending_mtx_);
             --pending_inflight_;
@@ -363,6 +380,8 @@ void DenseFlow::enqueue_pending(std::unique_ptr<PendingFlows> p) {
     unique_lock<mutex> lock(pending_mtx_);
     // at most two FlowBuffers of flows wait for their tails: the one just submitted and the one before it
     pending_cv_.wait(lock, [&] { return pending_inflight_ < 2; });
+    if (!pending_error_.empty()) // an earlier FlowBuffer's tail failed: stop at once, nothing more is saved
+        throw std::runtime_error(pending_error_);
     ++pending_inflight_;
     pending_q_.push(std::move(p));
     pending_cv_.notify_all();

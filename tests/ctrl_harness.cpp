@@ -73,15 +73,15 @@ extern "C" int ctrl_replay_level_ex(const float *I0, const float *I1, float *u1,
 // step kernel and its launcher use).  Returns 0 when (1) every image pixel is owned by exactly one tile, (2) every
 // owned pixel's dependency cone of `halo` pixels lies inside its tile or outside the image (so the tile's recomputed
 // values are the exact ones), (3) the step's tile count does not exceed the launched grid; otherwise a code > 0.
-extern "C" int ctrl_geometry_check(int w, int h, int tw, int th, int K, int n_iters, int geom, int split_warp,
-                                   int *n_tiles_out, int *grid_out) {
-    const Tvl1StepGeom g = tvl1_step_geom(w, h, tw, th, K, n_iters, geom);
-    const int nt = g.ntx * g.nty, grid = tvl1_step_grid(w, h, tw, th, K, geom, split_warp);
+extern "C" int ctrl_geometry_check(int w, int h, int tw, int th, int K, int shift, int split_warp, int *n_tiles_out,
+                                   int *grid_out) {
+    const Tvl1StepGeom g = tvl1_step_geom(w, h, tw, th, K, split_warp ? shift : 0);
+    const int nt = g.ntx * g.nty, grid = tvl1_step_grid(w, h, tw, th, K, shift, split_warp);
     *n_tiles_out = nt;
     *grid_out = grid;
     if (nt > grid || nt < 1)
         return 3;
-    if (g.halo != ((geom & 2) ? (n_iters < K ? n_iters : K) : K))
+    if (g.halo != K)
         return 4;
     std::vector<unsigned char> owner((size_t)w * h, 0);
     for (int t = 0; t < nt; ++t) {

@@ -55,3 +55,19 @@ def test_create_rejects_bad_arguments_or_reports_no_device(dfx):
         with pytest.raises(dfx.DfxError) as e:
             dfx.FlowEngine(64, 48)
         assert e.value.status == 2 and "no CPU fallback" in str(e.value)
+
+
+def test_the_library_reads_no_environment_and_the_product_tvl1_file_stays_small():
+    """every A/B switch is a dfx_params field (variant / step_group / tvl1_math), libdfx.so reads no
+    environment variable, and the rejected TVL1 kernel variants are gone from the product library."""
+    import glob
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "denseflow_amd", "csrc", "*")):
+        with open(path) as f:
+            text = f.read()
+        assert not re.search(r"\bgetenv\s*\(", text), f"{os.path.basename(path)} reads the environment"
+    with open(os.path.join(root, "denseflow_amd", "csrc", "tvl1_kernels.hip")) as f:
+        assert len(f.read().splitlines()) <= 1300

@@ -78,23 +78,27 @@ def test_large_pyramid_1080p(dfx, oracle):
     assert np.abs(out - gt)[64:-64, 64:-64].mean() < 0.05
 
 
-@pytest.mark.parametrize("sor_mode", [0, 1, 2])
-def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle, sor_mode, monkeypatch):
-    """The fused SOR kernel (LDS tile, recomputed halo, several sweeps per launch) must not change a bit
-    relative to the simple form, for even and odd solver-iteration counts — with two barriers per half sweep (mode 0),
-    with one (mode 1), and with the wavefronts of dead halo rows skipping their updates (mode 2)."""
-    monkeypatch.setenv("DFX_BROX_SOR", str(sor_mode))
+@pytest.mark.parametrize("variant", ["r3", "r2"])
+def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle, variant):
+    """The fused SOR kernels (LDS tile, recomputed halo, five sweeps per launch) must not change a bit relative to the
+    simple one-launch-per-half-sweep form, for even and odd solver-iteration counts: the round-3 default (8-byte loads,
+    the two pixels of a half sweep as packed float2 math, exact Newton reciprocals) and the round-2 kernel it replaced
+    (dfx_params.variant = DFX_VAR_BROX_SOR_R2)."""
+    from denseflow_amd import engine as E
+
+    knobs = {"variant": E.VAR_BROX_SOR_R2} if variant == "r2" else {}
     # large enough that workgroups of one launch are NOT all co-resident: an in-place update of du/dv would
-    # race with neighbours reading their halo (this caught exactly that bug; the kernel ping-pongs two sets)
-    w, h = 1000, 600
-    clip = SynthClip(w, h, 8)
-    f0, f1 = clip.frame(0), clip.frame(1)
-    for solver in (10, 3, 7):
-        with dfx.FlowEngine(w, h, "brox", impl=1, brox_solver_iterations=solver) as eng:
-            simple = eng.calc(f0, f1)
-        with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver) as eng:
-            fused = eng.calc(f0, f1)
-        assert np.array_equal(simple, fused), solver
+    # race with neighbours reading their halo (this caught exactly that bug; the kernels ping-pong two sets).
+    # odd width and height: the right-most 8-byte pair and the last patch row straddle the image border
+    for (w, h, seed) in ((1000, 600, 8), (333, 201, 5)):
+        clip = SynthClip(w, h, seed)
+        f0, f1 = clip.frame(0), clip.frame(1)
+        for solver in (10, 3, 7):
+            with dfx.FlowEngine(w, h, "brox", impl=1, brox_solver_iterations=solver) as eng:
+                simple = eng.calc(f0, f1)
+            with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver, **knobs) as eng:
+                fused = eng.calc(f0, f1)
+            assert np.array_equal(simple.view(np.uint32), fused.view(np.uint32)), (w, h, solver)
 
 
 def test_config5_shape_4k_step2(dfx, oracle):

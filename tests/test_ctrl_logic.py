@@ -72,12 +72,12 @@ def test_state_machine_replays_oracle(oracle, harness, fuse_k, w, h, seed, dt, i
         assert steps.value <= int(iters[:5].sum())
 
 
-@pytest.mark.parametrize("geom", [0, 1, 2, 3])
-def test_step_tile_geometry_partitions_the_image(harness, geom):
-    """The step kernel's optional tile geometries (tvl1_ctrl.h: tile columns from x = 0, halo as wide as the step is
-    long): every pixel has exactly one owning tile, owned pixels never depend on values outside their tile, and no
-    step needs more workgroups than the launcher provides — for the 1080p pyramid, degenerate sizes and random ones."""
-    harness.ctrl_geometry_check.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_int)] * 2
+@pytest.mark.parametrize("shift", [0, 1])
+def test_step_tile_geometry_partitions_the_image(harness, shift):
+    """The step kernel's tile geometries (tvl1_ctrl.h: the default with tile columns from x = 0, and the classic one):
+    every pixel has exactly one owning tile, owned pixels never depend on values outside their tile, and the launcher
+    provides exactly the step's tiles — for the 1080p pyramid, degenerate sizes and random ones."""
+    harness.ctrl_geometry_check.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_int)] * 2
     harness.ctrl_geometry_check.restype = C.c_int
     rng = np.random.default_rng(7)
     sizes = [(1920, 1080), (1536, 864), (1229, 691), (983, 553), (786, 442), (224, 224), (16, 16), (57, 40), (64, 64),
@@ -86,19 +86,14 @@ def test_step_tile_geometry_partitions_the_image(harness, geom):
     nt, grid = C.c_int(0), C.c_int(0)
     for (w, h) in sizes:
         for k in (1, 2, 3, 4, 6, 12):
-            for n in range(1, k + 1):
-                if w * h > 500_000 and (k != 4 or n not in (2, 4)):
-                    continue
-                for split in (0, 1):
-                    rc = harness.ctrl_geometry_check(w, h, 64, 32, k, n, geom, split, C.byref(nt), C.byref(grid))
-                    assert rc == 0, (w, h, k, n, geom, split, rc, nt.value, grid.value)
-    # what the geometries buy at the 1080p pyramid (K = 4): tile counts of a full step and of a 2-iteration step
-    want = {0: (285, 285), 1: (266, 266), 2: (285, 224), 3: (266, 224)}[geom]
-    got = []
-    for n in (4, 2):
-        assert harness.ctrl_geometry_check(786, 442, 64, 32, 4, n, geom, 1, C.byref(nt), C.byref(grid)) == 0
-        got.append(nt.value)
-    assert tuple(got) == want
+            if w * h > 500_000 and k != 4:
+                continue
+            for split in (0, 1):
+                rc = harness.ctrl_geometry_check(w, h, 64, 32, k, shift, split, C.byref(nt), C.byref(grid))
+                assert rc == 0 and nt.value == grid.value, (w, h, k, shift, split, rc, nt.value, grid.value)
+    # what the default buys at the coarsest 1080p level (K = 4): 14 instead of 15 tile columns
+    assert harness.ctrl_geometry_check(786, 442, 64, 32, 4, shift, 1, C.byref(nt), C.byref(grid)) == 0
+    assert nt.value == {0: 285, 1: 266}[shift]
 
 
 def test_xcd_aware_tile_mapping_is_a_bijection(harness):

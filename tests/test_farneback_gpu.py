@@ -105,22 +105,21 @@ def test_device_resident_entry_point(dfx):
 
 
 @pytest.mark.parametrize("w,h,seed", [(256, 128, 3), (640, 360, 4), (97, 61, 9), (33, 40, 2), (1920, 1080, 2)])
-def test_frame_preparation_variants_do_not_change_a_bit(dfx, oracle, w, h, seed, monkeypatch):
+def test_frame_preparation_variants_do_not_change_a_bit(dfx, oracle, w, h, seed):
     """Two restructurings of the per-frame kernels keep every bit: bilinear pyramid taps whose weight is exactly 0 are
-    not evaluated (DFX_FARN_SKIP0: 3 of 4 taps wherever the level's size divides the frame's), and the polynomial
-    expansion walks 16 rows per workgroup with its vertical window in registers (DFX_FARN_POLYROWS)."""
+    not evaluated (3 of 4 taps wherever the level's size divides the frame's; DFX_VAR_FARN_EVAL_ZERO_TAPS evaluates
+    them), and the polynomial expansion walks 16 rows per workgroup with its vertical window in registers
+    (DFX_VAR_FARN_POLY_ONE_ROW: the first form)."""
+    from denseflow_amd import engine as E
+
     clip = SynthClip(w, h, seed)
     frames = clip.frames(4)
-    monkeypatch.setenv("DFX_FARN_SKIP0", "0")
-    monkeypatch.setenv("DFX_FARN_POLYROWS", "0")
-    with dfx.FlowEngine(w, h, "farn", max_batch=2) as eng:
+    with dfx.FlowEngine(w, h, "farn", max_batch=2, variant=E.VAR_FARN_EVAL_ZERO_TAPS | E.VAR_FARN_POLY_ONE_ROW) as eng:
         base = eng.calc_optflows(frames, 1)
     if w * h <= 640 * 360:
         assert np.array_equal(base[0], oracle.farneback_calc(frames[0], frames[1]))
-    for skip, rows in ((1, 0), (0, 16), (1, 16)):
-        monkeypatch.setenv("DFX_FARN_SKIP0", str(skip))
-        monkeypatch.setenv("DFX_FARN_POLYROWS", str(rows))
-        with dfx.FlowEngine(w, h, "farn", max_batch=2) as eng:
+    for variant in (E.VAR_FARN_POLY_ONE_ROW, E.VAR_FARN_EVAL_ZERO_TAPS, 0):
+        with dfx.FlowEngine(w, h, "farn", max_batch=2, variant=variant) as eng:
             out = eng.calc_optflows(frames, 1)
         for i, (a, b) in enumerate(zip(out, base)):
-            assert np.array_equal(a, b), f"skip0={skip} polyrows={rows}: pair {i} changed"
+            assert np.array_equal(a, b), f"variant={variant}: pair {i} changed"
