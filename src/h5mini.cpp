@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <unordered_set>
 
 namespace h5mini {
 namespace {
@@ -338,12 +339,30 @@ void append(const std::string &path, const std::vector<FloatDataset> &datasets) 
     if (!fc.f)
         fail(path, "cannot open");
     Index ix = read_index(fc.f, path);
-    Writer w{fc.f, path, (ix.eof + 7) & ~7ull};
+    // Where the new datasets go.  This writer lays a file out as [superblock, root header][datasets ...][index], the index
+    // (local heap, then the symbol table nodes, then the B-tree whose root node is written last) being rewritten by every
+    // append.  When the old index is that tail — heap first, above every dataset header, root node ending at the
+    // end-of-file address — the new datasets overwrite it and the new index follows them: the file grows by the data
+    // it holds, not quadratically by one abandoned index per FlowBuffer.  (A file whose group structures sit elsewhere,
+    // e.g. one created by libhdf5 itself, is appended to at its end once and has the tail layout from then on.)
+    uint64_t start = (ix.eof + 7) & ~7ull;
+    {
+        const uint64_t fan = 2 * (uint64_t)ix.internal_k;
+        const uint64_t root_end = (ix.btree + 24 + fan * 8 + (fan + 1) * 8 + 7) & ~7ull;
+        uint64_t hdr_hi = ix.root_header + 16 + 24; // end of the root object header written by create()
+        for (const Entry &e : ix.entries)
+            hdr_hi = std::max(hdr_hi, e.header_addr + 16 + 128); // a dataset header of dataset_header() is 136 bytes
+        if (ix.heap < ix.btree && ix.heap >= hdr_hi && root_end == start)
+            start = ix.heap;
+    }
+    Writer w{fc.f, path, start};
+    std::unordered_set<std::string> names;
+    for (const Entry &e : ix.entries)
+        names.insert(e.name);
     std::vector<uint8_t> row;
     for (const FloatDataset &d : datasets) {
-        for (const Entry &e : ix.entries)
-            if (e.name == d.name)
-                fail(path, ("dataset exists: " + d.name).c_str());
+        if (!names.insert(d.name).second)
+            fail(path, ("dataset exists: " + d.name).c_str());
         const uint64_t data_addr = w.pos;
         if (d.pitch_bytes == d.cols * sizeof(float)) {
             pwrite_exact(fc.f, path, data_addr, d.data, d.rows * d.cols * sizeof(float));

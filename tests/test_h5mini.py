@@ -158,3 +158,30 @@ def test_appending_to_a_file_created_by_libhdf5(h5h, tmp_path):
     rc, msg = _append(h5h, p, names, arr)
     assert rc == 0, msg
     _check(p, {n: arr[i] for i, n in enumerate(names)})
+
+
+def test_many_flowbuffers_grow_the_file_linearly(h5h, tmp_path):
+    """Every append rewrites the group's index (heap + symbol table nodes + B-tree).  The old index is overwritten by
+    the new datasets instead of being abandoned (the file grew roughly quadratically in the number of
+    FlowBuffers): after 60 appends the file holds the data, ONE index and nothing else — and still reads back."""
+    p = str(tmp_path / "long.h5")
+    err = C.create_string_buffer(512)
+    assert h5h.h5h_create(p.encode(), err, 512) == 0
+    rng = np.random.default_rng(9)
+    expect, n_buffers, per = {}, 60, 8
+    sizes = []
+    for b in range(n_buffers):
+        for phase in ("flow_x", "flow_y"):
+            names = ["%s_%05d" % (phase, b * per + i) for i in range(per)]
+            arr = rng.standard_normal((per, 5, 9)).astype(np.float32)
+            rc, msg = _append(h5h, p, names, arr)
+            assert rc == 0, msg
+            expect.update({n: arr[i] for i, n in enumerate(names)})
+        sizes.append(os.path.getsize(p))
+    n = 2 * n_buffers * per
+    data_bytes = n * (5 * 9 * 4 + 4 + 144)           # data (padded to 8) + one 144-byte object header per dataset
+    index_bytes = 32 + 8 + n * 24 + 16 + ((n + 511) // 512) * (8 + 512 * 40) + 24 + 32 * 8 + 33 * 8
+    assert sizes[-1] <= 96 + 40 + data_bytes + index_bytes + 64, (sizes[-1], data_bytes, index_bytes)
+    growth = np.diff(sizes)
+    assert growth.max() <= 2 * (2 * per * (5 * 9 * 4 + 4 + 144 + 24)) + 8 + 512 * 40 + 64  # no term that grows with b
+    _check(p, expect)
