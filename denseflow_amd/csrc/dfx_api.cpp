@@ -9,7 +9,6 @@
 #include <cstring>
 
 #include "dfx_internal.h"
-#include "egress_kernels.h"
 #include "prepare_kernels.h"
 #include "quantize_kernels.h"
 
@@ -152,35 +151,6 @@ int ensure_bounce(dfx_context *c, size_t in_bytes, size_t out_bytes) {
         c->h_out_bytes = out_bytes;
     }
     return DFX_OK;
-}
-
-int ensure_egress(dfx_context *c, int items) {
-    if (items > c->egress_cap) {
-        (void)dfx_finish_tails(c, 0, -1);
-        HIPCHK(c, hipDeviceSynchronize());
-        c->egress_cap = 0;
-        for (auto &p : c->h_egress) {
-            dfx_free_host(p);
-            HIPCHK(c, hipHostMalloc(&p, sizeof(EgressItem) * (size_t)items, hipHostMallocDefault));
-        }
-        c->egress_cap = items;
-    }
-    return DFX_OK;
-}
-
-// The device's address of page-locked host memory the caller handed in, or nullptr when the device cannot write there
-// (pageable memory: hipMemcpyAsync stages it).
-void *device_view_of_host(const void *p) {
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
-        (void)hipGetLastError(); // not a registered pointer: clear the sticky error
-        return nullptr;
-    }
-    if (a.type != hipMemoryTypeHost || !a.devicePointer || !a.hostPointer)
-        return nullptr;
-    // (hostPointer, devicePointer) describe the same byte — the queried one or the allocation's first, depending on the
-    // runtime; the offset between p and hostPointer carries over either way
-    return (char *)a.devicePointer + ((const char *)p - (const char *)a.hostPointer);
 }
 
 int ensure_staging(dfx_context *c, int u8_need, int flow_need) {
@@ -358,35 +328,10 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         HIPCHK(c, hipEventRecord(c->ev_h2d[par(k)], c->copy_stream));
         return DFX_OK;
     };
-    // Device-to-host leg: the copy kernel of this library (egress_kernels.hip: a few persistent workgroups — a
-    // hipMemcpyAsync device-to-host is a machine-filling shader blit here and slows the batch computing beside it by a
-    // third) whenever every destination of the batch is page-locked memory the device can write with 16-byte stores;
-    // hipMemcpyAsync otherwise (pageable or oddly aligned buffers), and with DFX_VAR_D2H_MEMCPY (A/B).
-    const bool egress_allowed = !(c->prm.variant & DFX_VAR_D2H_MEMCPY);
-    const int egress_wgs = c->prm.egress_workgroups > 0 ? c->prm.egress_workgroups : 48;
-    auto try_egress = [&](int q, std::vector<EgressItem> &items) -> int { // 1 = launched, 0 = not applicable, < 0 error
-        if (!egress_allowed || items.empty())
-            return 0;
-        for (EgressItem &it : items) {
-            it.dst = device_view_of_host(it.dst);
-            if (!it.dst || !egress_item_ok(it))
-                return 0;
-        }
-        if (ensure_egress(c, (int)items.size()) != DFX_OK)
-            return -1;
-        std::memcpy(c->h_egress[q], items.data(), sizeof(EgressItem) * items.size());
-        if (egress_launch(c->d2h_stream, c->h_egress[q], (int)items.size(), egress_wgs)) {
-            if (hipGetLastError() != hipSuccess)
-                return -1;
-            c->stats.kernel_launches += 1;
-        }
-        return 1;
-    };
     auto download = [&](size_t k) -> int { // flows of batch k: staging set par(k) -> host (download stream)
         const BatchPlan &p = plan[k];
         const int q = par(k);
         HIPCHK(c, hipStreamWaitEvent(c->d2h_stream, c->ev_compute[q], 0));
-        std::vector<EgressItem> items;
         if (bounce) { // one block per plane kind; scatter(k) hands the rows to the caller's buffers later
             // a deferred tail of an earlier FlowBuffer may still have to empty this bounce buffer
             const int trc = dfx_finish_tails(c, 0, q);
@@ -394,25 +339,12 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 return trc;
             unsigned char *hb = c->h_out[q];
             if (out.quantized) {
-                const size_t n = (size_t)p.nb * plane;
-                items.push_back(EgressItem{hb, c->d_img[q], n, n, n, 1u, 0u});
-                items.push_back(EgressItem{hb + n, c->d_img[q] + (size_t)c->img_slots * plane, n, n, n, 1u, 0u});
+                HIPCHK(c, hipMemcpyAsync(hb, c->d_img[q], (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->d2h_stream));
+                HIPCHK(c, hipMemcpyAsync(hb + (size_t)p.nb * plane, c->d_img[q] + (size_t)c->img_slots * plane,
+                                         (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->d2h_stream));
             } else {
-                const size_t n = (size_t)p.nb * plane * 8;
-                items.push_back(EgressItem{hb, c->d_flow_out[q], n, n, n, 1u, 0u});
-            }
-            const int er = try_egress(q, items);
-            if (er < 0)
-                return dfx_fail(c, DFX_ERR_HIP, "device-to-host copy kernel failed to launch");
-            if (er == 0) {
-                if (out.quantized) {
-                    HIPCHK(c, hipMemcpyAsync(hb, c->d_img[q], (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->d2h_stream));
-                    HIPCHK(c, hipMemcpyAsync(hb + (size_t)p.nb * plane, c->d_img[q] + (size_t)c->img_slots * plane,
-                                             (size_t)p.nb * plane, hipMemcpyDeviceToHost, c->d2h_stream));
-                } else {
-                    HIPCHK(c, hipMemcpyAsync(hb, c->d_flow_out[q], (size_t)p.nb * plane * 8, hipMemcpyDeviceToHost,
-                                             c->d2h_stream));
-                }
+                HIPCHK(c, hipMemcpyAsync(hb, c->d_flow_out[q], (size_t)p.nb * plane * 8, hipMemcpyDeviceToHost,
+                                         c->d2h_stream));
             }
             HIPCHK(c, hipEventRecord(c->ev_d2h[q], c->d2h_stream));
             return DFX_OK;
@@ -421,30 +353,14 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             if (out.quantized) {
                 const unsigned char *sx = c->d_img[q] + (size_t)j * plane;
                 const unsigned char *sy = c->d_img[q] + ((size_t)c->img_slots + j) * plane;
-                items.push_back(EgressItem{out.img_x[p.i0 + j], sx, out.img_pitch, (size_t)c->W, (size_t)c->W, (unsigned)c->H, 0u});
-                items.push_back(EgressItem{out.img_y[p.i0 + j], sy, out.img_pitch, (size_t)c->W, (size_t)c->W, (unsigned)c->H, 0u});
+                HIPCHK(c, copy_rows_async(out.img_x[p.i0 + j], out.img_pitch, sx, c->W, c->W, c->H,
+                                          hipMemcpyDeviceToHost, c->d2h_stream));
+                HIPCHK(c, copy_rows_async(out.img_y[p.i0 + j], out.img_pitch, sy, c->W, c->W, c->H,
+                                          hipMemcpyDeviceToHost, c->d2h_stream));
             } else {
-                items.push_back(EgressItem{out.flows[p.i0 + j], c->d_flow_out[q] + (size_t)j * plane * 2, out.out_pitch,
-                                           (size_t)c->W * 8, (size_t)c->W * 8, (unsigned)c->H, 0u});
-            }
-        }
-        const int er = try_egress(q, items);
-        if (er < 0)
-            return dfx_fail(c, DFX_ERR_HIP, "device-to-host copy kernel failed to launch");
-        if (er == 0) {
-            for (int j = 0; j < p.nb; ++j) {
-                if (out.quantized) {
-                    const unsigned char *sx = c->d_img[q] + (size_t)j * plane;
-                    const unsigned char *sy = c->d_img[q] + ((size_t)c->img_slots + j) * plane;
-                    HIPCHK(c, copy_rows_async(out.img_x[p.i0 + j], out.img_pitch, sx, c->W, c->W, c->H,
-                                              hipMemcpyDeviceToHost, c->d2h_stream));
-                    HIPCHK(c, copy_rows_async(out.img_y[p.i0 + j], out.img_pitch, sy, c->W, c->W, c->H,
-                                              hipMemcpyDeviceToHost, c->d2h_stream));
-                } else {
-                    HIPCHK(c, copy_rows_async(out.flows[p.i0 + j], out.out_pitch,
-                                              c->d_flow_out[q] + (size_t)j * plane * 2, (size_t)c->W * 8, (size_t)c->W * 8,
-                                              c->H, hipMemcpyDeviceToHost, c->d2h_stream));
-                }
+                HIPCHK(c, copy_rows_async(out.flows[p.i0 + j], out.out_pitch, c->d_flow_out[q] + (size_t)j * plane * 2,
+                                          (size_t)c->W * 8, (size_t)c->W * 8, c->H, hipMemcpyDeviceToHost,
+                                          c->d2h_stream));
             }
         }
         HIPCHK(c, hipEventRecord(c->ev_d2h[q], c->d2h_stream));
@@ -1070,8 +986,6 @@ void dfx_destroy(dfx_handle h) {
     for (auto &p : h->h_in)
         dfx_free_host(p);
     for (auto &p : h->h_out)
-        dfx_free_host(p);
-    for (auto &p : h->h_egress)
         dfx_free_host(p);
     for (auto &e : h->ev_h2d)
         if (e)

@@ -24,7 +24,6 @@
 //     run_pairs     - compute `nb` flows (pair -> frame-slot descriptors) into d_out
 //     account       - fold the finished batch into dfx_stats (after the stream is synchronised)
 struct dfx_context;
-struct EgressItem;
 
 class AlgoEngine {
   public:
@@ -87,9 +86,6 @@ struct dfx_context {
     size_t h_in_bytes = 0, h_out_bytes = 0;
     unsigned char *d_img[2] = {nullptr, nullptr}; // bounded output: img_slots x planes, then img_slots y planes
     int img_slots = 0;
-    // descriptors of the device-to-host copy kernel (egress_kernels.hip), page-locked, one array per staging parity
-    EgressItem *h_egress[2] = {nullptr, nullptr};
-    int egress_cap = 0;
     std::vector<int> h_slots;      // slot id of each new frame of the current batch
     std::vector<PairDesc> h_pairs; // descriptors of the current batch
 

@@ -503,27 +503,23 @@ __global__ __launch_bounds__(256) void k_farn_iteration(FarnPairCtx c, int flow_
 // The same iteration for a compile-time box half-width, restructured around LDS traffic and latency:
 //   * 64 x 32 output pixels per workgroup: the halo re-read of M drops from 2.08x to 1.63x;
 //   * the halo tile of plane p+1 is fetched into registers while plane p is being summed;
-//   * vertical sums: one thread owns an 8-row strip of one tile column and keeps its 8 + 2*HALF inputs in
-//     registers (2.5 LDS reads per sum instead of 2*HALF + 1);
+//   * vertical sums: one thread owns a 10- or 12-row strip of one tile column and keeps its inputs in registers
+//     (about two LDS reads per sum instead of 2*HALF + 1), one pass, one strip per wave: no bank conflicts (round 3;
+//     measured equal to round 2's two-pass form within the run-to-run noise — the kernel is bound by its HBM
+//     traffic, 62 B per pixel at ~4.5 TB/s, not by LDS: profiles/round3/experiments/farn_iteration_kernel_ab.txt —
+//     kept because it needs 110 instead of 126 VGPRs and is the simpler code);
+//   * the halo tile is fetched as 8-byte column pairs wherever its columns need no clamping;
 //   * horizontal sums: one thread owns an 8-column strip of one row, read with 16-byte LDS loads (row pitch
 //     = 4 mod 32 words keeps the lanes of a wave, which walk down the rows, on distinct banks); the 8 results
 //     go back through a small LDS array so that the solve / updateMatrices phase sees lane = x again.
 // Every sum is still  centre + (left_1 + right_1) + (left_2 + right_2) ...  in upstream's order (B.8).
-#ifndef FARN_IT_ROW_FENCE
-#define FARN_IT_ROW_FENCE 1
-#endif
-#ifndef FARN_IT_WGS
-#define FARN_IT_WGS 5 // workgroups per CU the register budget of the iteration kernel is set for
-#endif
 template <int HALF>
-__global__ __launch_bounds__(256, FARN_IT_WGS) void k_farn_iteration_t(FarnPairCtx c, int flow_set, int m_src,
-                                                                       float box_inv, int do_matrices) {
+__global__ __launch_bounds__(256) void k_farn_iteration_t(FarnPairCtx c, int flow_set, int m_src, float box_inv,
+                                                          int do_matrices) {
     constexpr int TW = 64, TH = 32, IW = TW + 2 * HALF, IH = TH + 2 * HALF;
-    // LDS: 13376 + 10752 + 8192 = 32320 B, i.e. FIVE workgroups per CU (round 2: 34880 B and 126 VGPRs = four).
-    constexpr int VP = 84; // pitch of the vertical-sum rows: >= 80 (six 16-byte reads from column cs <= 56), 16-byte rows,
-                           // and 84 = 20 (mod 64) puts the 16 lanes of every ds_read_b128 group on distinct 4-bank slots
-    constexpr int HP = TW; // pitch of the result rows; column XOR-swizzled by 8 * (row & 7) instead of padded
     static_assert(HALF == 6 && TH == 32, "the strip / bank layout of the vertical pass is worked out for a 76 x 44 halo tile");
+    constexpr int VP = ((IW + 27) / 32) * 32 + 4; // pitch of the vertical-sum rows: >= IW, = 4 mod 32, 16-B rows
+    constexpr int HP = TW + 4;                    // pitch of the result rows
     __shared__ __attribute__((aligned(16))) float tile[IH][IW];
     __shared__ __attribute__((aligned(16))) float vs[TH][VP];
     __shared__ __attribute__((aligned(16))) float hb[TH][HP];
@@ -532,14 +528,13 @@ __global__ __launch_bounds__(256, FARN_IT_WGS) void k_farn_iteration_t(FarnPairC
     const DfxBlockXY blk = dfx_block_xy(); // the 76 x 44 halo tiles of neighbours overlap (M is read 1.63 x): one L2
     const int x0 = blk.x * TW, y0 = blk.y * TH;
     const int w = c.L.w, h = c.L.h, pitch = c.L.pitch;
+    const float *Mbase = farn_plane(c, b, m_src ? FARN_PL_M1 : FARN_PL_M0);
 
     // The halo tile is fetched as pairs of columns.  x0 - HALF is even and the pitch a multiple of 64, so wherever the
-    // 76 halo columns need no clamping (every tile but the first / last of a row) a pair is ONE 8-byte load: 7 load
-    // instructions and 7 offsets per thread and plane (round 2: 14 dword loads and 14 offsets — the registers that kept
-    // the kernel at four workgroups per CU).  Tiles that touch the left / right border clamp per element and recompute
-    // their offsets for every plane (a few hundred VALU instructions on 2 of 30 tile columns at 1080p).
-    constexpr int NE2 = IW / 2 * IH;          // column pairs of the halo tile
-    constexpr int NLD2 = (NE2 + 255) / 256;   // pairs per thread
+    // 76 halo columns need no clamping (every tile but the first / last of a row) a pair is ONE 8-byte load.  Tiles that
+    // touch the left / right border clamp per element and recompute their offsets for every plane.
+    constexpr int NE2 = IW / 2 * IH;        // column pairs of the halo tile
+    constexpr int NLD2 = (NE2 + 255) / 256; // pairs per thread
     const bool xin = x0 >= HALF && x0 + TW + HALF <= w;
     int off2[NLD2];
 #pragma unroll
@@ -548,7 +543,6 @@ __global__ __launch_bounds__(256, FARN_IT_WGS) void k_farn_iteration_t(FarnPairC
         const int ty = e / (IW / 2), tx = 2 * (e - ty * (IW / 2));
         off2[k] = min(max(y0 - HALF + ty, 0), h - 1) * pitch + (x0 - HALF + tx); // rows clamp, columns do not (xin)
     }
-    const float *Mbase = farn_plane(c, b, m_src ? FARN_PL_M1 : FARN_PL_M0);
     float pre[2 * NLD2];
     auto fetch = [&](const float *Mp) {
         if (xin) {
@@ -585,14 +579,6 @@ __global__ __launch_bounds__(256, FARN_IT_WGS) void k_farn_iteration_t(FarnPairC
 
     // Vertical sums of one column over a strip of NR rows starting at tile row r0: NR + 2 * HALF inputs in registers
     // (about two LDS reads per sum instead of 13), upstream's order (centre + (up_1 + down_1) + (up_2 + down_2) ...).
-    // Round 2 dealt 76 columns x four 8-row strips = 304 items over 256 threads: a second pass with 48 busy lanes, and
-    // every wave but the first straddled two strips whose tile rows are 8 * 76 = 0 (mod 32) words apart — two-way bank
-    // conflicts on all of its reads (SQ_LDS_BANK_CONFLICT was 39 % of the LDS busy time).  Now ONE pass: waves 0, 1, 2
-    // take columns 0..63 of three strips of 12 / 10 / 10 rows (one strip per wave: consecutive lanes, consecutive
-    // banks), wave 3 the 12 halo columns 64..75 of all three strips — as 12-row items starting at rows 0 / 10 / 20 so
-    // that its lanes run one code path (rows 10, 11, 20, 21 are written twice with the same values), placed so that
-    // items of one half-wave are >= 12 banks apart: rows 0 and 20 (20 * 76 = 16 mod 32) in lanes 0-11 / 12-23, row 10
-    // (10 * 76 = 24 mod 32) in lanes 32-43.
     auto vstrip = [&](auto nr, int r0, int col) {
         constexpr int NR = decltype(nr)::value;
         float v[NR + 2 * HALF];
@@ -608,6 +594,12 @@ __global__ __launch_bounds__(256, FARN_IT_WGS) void k_farn_iteration_t(FarnPairC
             vs[r0 + i][col] = a;
         }
     };
+    // ONE pass: waves 0, 1, 2 take columns 0..63 of three strips of 12 / 10 / 10 rows (one strip per wave: consecutive
+    // lanes, consecutive banks), wave 3 the 12 halo columns 64..75 of all three strips — as 12-row items starting at rows
+    // 0 / 10 / 20 so that its lanes run one code path (rows 10, 11, 20, 21 are written twice with the same values),
+    // placed so that items of one half-wave are >= 12 banks apart: rows 0 and 20 (20 * 76 = 16 mod 32) in lanes 0-11 /
+    // 12-23, row 10 (10 * 76 = 24 mod 32) in lanes 32-43.  (Round 2's second pass kept 48 lanes busy, and every wave but
+    // the first straddled two strips whose tile rows are 8 * 76 = 0 (mod 32) words apart: two-way bank conflicts.)
     const int v3_row0 = lane < 12 ? 0 : lane < 24 ? 20 : (lane >= 32 && lane < 44) ? 10 : -1;
     const int v3_col = TW + (lane < 12 ? lane : lane < 24 ? lane - 12 : lane - 32);
 
@@ -616,8 +608,6 @@ __global__ __launch_bounds__(256, FARN_IT_WGS) void k_farn_iteration_t(FarnPairC
     for (int p = 0; p < 5; ++p) {
         if (p + 1 < 5) // in flight during the vertical pass
             fetch(Mbase + (long long)(p + 1) * c.plane_stride);
-        // vertical sums (see vstrip above): waves 0..2 = columns 0..63 of the strips starting at rows 0 / 12 / 22,
-        // wave 3 = the 12 halo columns of all three
         if (wave == 0)
             vstrip(std::integral_constant<int, 12>{}, 0, lane);
         else if (wave < 3)
@@ -645,14 +635,14 @@ __global__ __launch_bounds__(256, FARN_IT_WGS) void k_farn_iteration_t(FarnPairC
                     a = a + (v[i + HALF - k] + v[i + HALF + k]);
                 r[i] = a * box_inv;
             }
-            float4 *dst = reinterpret_cast<float4 *>(&hb[row][cs ^ ((row & 7) * 8)]);
+            float4 *dst = reinterpret_cast<float4 *>(&hb[row][cs]);
             dst[0] = make_float4(r[0], r[1], r[2], r[3]);
             dst[1] = make_float4(r[4], r[5], r[6], r[7]);
         }
         __syncthreads(); // B: hb complete, vs free, next tile visible
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            m[p][i] = hb[wave * 8 + i][lane ^ (i * 8)]; // row & 7 == i
+            m[p][i] = hb[wave * 8 + i][lane];
     }
 
     const int x = x0 + lane;
@@ -681,9 +671,6 @@ __global__ __launch_bounds__(256, FARN_IT_WGS) void k_farn_iteration_t(FarnPairC
             for (int p = 0; p < 5; ++p)
                 farn_plane(c, b, (m_src ? FARN_PL_M0 : FARN_PL_M1) + p)[o] = M[p];
         }
-#if FARN_IT_ROW_FENCE
-        __builtin_amdgcn_sched_barrier(0); // one row's gathers at a time: the register budget of five workgroups per CU
-#endif
     }
 }
 

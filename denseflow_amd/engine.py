@@ -62,7 +62,6 @@ class DfxParams(C.Structure):
         ("tvl1_math", C.c_int),
         ("variant", C.c_int),
         ("step_group", C.c_int),
-        ("egress_workgroups", C.c_int),
     ]
 
 
@@ -70,7 +69,6 @@ class DfxParams(C.Structure):
 VAR_TVL1_CLASSIC_GEOM, VAR_TVL1_WARP_IN_STEP = 0x01, 0x02
 VAR_FARN_EVAL_ZERO_TAPS, VAR_FARN_POLY_ONE_ROW = 0x04, 0x08
 VAR_BROX_SOR_R2 = 0x10
-VAR_D2H_MEMCPY = 0x20
 
 
 class DfxStats(C.Structure):
