@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "dfx_internal.h"
+#include "jpeg_kernels.h"
 #include "prepare_kernels.h"
 #include "quantize_kernels.h"
 
@@ -129,6 +130,58 @@ int ensure_src_staging(dfx_context *c, int need) {
     return DFX_OK;
 }
 
+void free_jpeg(dfx_context *c) {
+    auto &j = c->jpeg;
+    dfx_free_dev(j.d_tab);
+    dfx_free_dev(j.d_dc);
+    dfx_free_dev(j.d_bits);
+    dfx_free_dev(j.d_plane_bits);
+    dfx_free_dev(j.d_plane_base);
+    dfx_free_dev(j.d_hdr);
+    for (int q = 0; q < 2; ++q) {
+        dfx_free_dev(j.d_stream[q]);
+        dfx_free_host(j.h_stream[q]);
+        dfx_free_host(j.h_info[q]);
+        j.d_info[q] = nullptr;
+    }
+    j.quality = j.pairs = 0;
+    j.capacity = 0;
+}
+
+// Buffers of the device JPEG encoder for batches of up to `pairs` pairs at `quality`.  The shared stream buffer holds
+// 4 bits per pixel on average over the batch (flow planes need ~0.5; a batch that does not fit is reported, not cut).
+int ensure_jpeg(dfx_context *c, int pairs, int quality) {
+    auto &j = c->jpeg;
+    if (j.quality == quality && pairs <= j.pairs)
+        return DFX_OK;
+    (void)dfx_finish_tails(c, 0, -1);
+    HIPCHK(c, hipDeviceSynchronize());
+    free_jpeg(c);
+    const size_t planes = 2 * (size_t)pairs, nblk = (size_t)((c->W + 7) / 8) * ((c->H + 7) / 8);
+    JpegTables t;
+    unsigned char q[64];
+    jpeg_build_tables(quality, t, q);
+    j.header = jpeg_file_header(c->W, c->H, q);
+    HIPCHK(c, hipMalloc(&j.d_tab, sizeof(JpegTables)));
+    HIPCHK(c, hipMemcpy(j.d_tab, &t, sizeof t, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&j.d_dc, planes * nblk * sizeof(short)));
+    HIPCHK(c, hipMalloc(&j.d_bits, planes * nblk * sizeof(unsigned)));
+    HIPCHK(c, hipMalloc(&j.d_plane_bits, planes * 8));
+    HIPCHK(c, hipMalloc(&j.d_plane_base, planes * 8));
+    HIPCHK(c, hipMalloc(&j.d_hdr, 16));
+    j.capacity = ((planes * (size_t)c->W * c->H / 2 + (64u << 10)) + 255) & ~(size_t)255;
+    for (int p = 0; p < 2; ++p) {
+        HIPCHK(c, hipMalloc(&j.d_stream[p], j.capacity));
+        HIPCHK(c, hipHostMalloc(&j.h_stream[p], j.capacity, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(&j.h_info[p], (2 + 2 * planes) * 8, hipHostMallocMapped));
+        std::memset(j.h_info[p], 0, (2 + 2 * planes) * 8);
+        HIPCHK(c, hipHostGetDevicePointer((void **)&j.d_info[p], j.h_info[p], 0));
+    }
+    j.quality = quality;
+    j.pairs = pairs;
+    return DFX_OK;
+}
+
 int ensure_bounce(dfx_context *c, size_t in_bytes, size_t out_bytes) {
     if (in_bytes > c->h_in_bytes) {
         (void)dfx_finish_tails(c, 0, -1);
@@ -191,6 +244,12 @@ struct OutSpec {
     size_t img_pitch = 0;                                     // bytes per row (host and device mode)
     uint8_t *d_img_x = nullptr, *d_img_y = nullptr;           // device mode: plane i at + i*d_img_stride
     size_t d_img_stride = 0;
+    // JPEG output (host mode; implies quantized): one file per plane into jpg_x[i] / jpg_y[i] (jpg_capacity bytes each)
+    bool jpeg = false;
+    int quality = 95;
+    uint8_t *const *jpg_x = nullptr, *const *jpg_y = nullptr;
+    size_t jpg_capacity = 0;
+    uint32_t *size_x = nullptr, *size_y = nullptr;
 };
 
 // One frame / plane between host and device.  Dense rows (pitch == row bytes on both sides) go as ONE linear copy:
@@ -254,6 +313,11 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         if (rc != DFX_OK)
             return rc;
     }
+    if (out.jpeg) {
+        rc = ensure_jpeg(c, B, out.quality);
+        if (rc != DFX_OK)
+            return rc;
+    }
     const size_t plane = (size_t)c->W * c->H;
     // Small frames: an asynchronous copy costs ~10 us of driver time whatever its size, and a 300-frame clip of
     // 224x224 frames is ~900 of them (a third of the batch's compute time).  Such FlowBuffers go through page-locked
@@ -264,7 +328,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     // Decided per direction: a 224x224 frame is 50 KB (gathered), but its float flow is 401 KB — one direct copy per
     // flow (~10 us of driver time) is cheaper than a second pass of host memcpy over 120 MB per clip.
     const bool bounce_in = host_mode && in_fb <= (256u << 10) && (size_t)(B + astep) * in_fb <= (256u << 20);
-    const bool bounce = bounce_in && out_pb <= (256u << 10) && (size_t)B * out_pb <= (256u << 20); // results
+    const bool bounce = !out.jpeg && bounce_in && out_pb <= (256u << 10) && (size_t)B * out_pb <= (256u << 20); // results
     if (bounce_in) {
         rc = ensure_bounce(c, (size_t)(B + astep) * in_fb, bounce ? (size_t)B * out_pb : 0);
         if (rc != DFX_OK)
@@ -328,10 +392,29 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         HIPCHK(c, hipEventRecord(c->ev_h2d[par(k)], c->copy_stream));
         return DFX_OK;
     };
+    // JPEG mode: what the device reported for each batch (read after the batch's stream synchronisation)
+    struct JpegBatch {
+        unsigned long long total = 0, overflow = 0;
+        std::vector<unsigned long long> bits, base; // per plane: x planes of the batch, then its y planes
+    };
+    std::vector<JpegBatch> jb(out.jpeg ? plan.size() : 0);
     auto download = [&](size_t k) -> int { // flows of batch k: staging set par(k) -> host (download stream)
         const BatchPlan &p = plan[k];
         const int q = par(k);
         HIPCHK(c, hipStreamWaitEvent(c->d2h_stream, c->ev_compute[q], 0));
+        if (out.jpeg) { // the batch's entropy-coded segments, one block; assemble_jpeg(k) turns them into files later
+            const int trc = dfx_finish_tails(c, 0, q); // a deferred tail may still be reading this landing buffer
+            if (trc != DFX_OK)
+                return trc;
+            if (jb[k].overflow)
+                return dfx_fail(c, DFX_ERR_UNSUPPORTED,
+                                "JPEG: the batch does not compress below 4 bits per pixel (use the 8-bit plane output)");
+            if (jb[k].total > 0)
+                HIPCHK(c, hipMemcpyAsync(c->jpeg.h_stream[q], c->jpeg.d_stream[q], (size_t)jb[k].total,
+                                         hipMemcpyDeviceToHost, c->d2h_stream));
+            HIPCHK(c, hipEventRecord(c->ev_d2h[q], c->d2h_stream));
+            return DFX_OK;
+        }
         if (bounce) { // one block per plane kind; scatter(k) hands the rows to the caller's buffers later
             // a deferred tail of an earlier FlowBuffer may still have to empty this bounce buffer
             const int trc = dfx_finish_tails(c, 0, q);
@@ -377,6 +460,19 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     auto scatter = [&](size_t k) -> int { // bounce mode: results of batch k -> the caller's buffers (host memcpy)
         const BatchPlan &p = plan[k];
         HIPCHK(c, hipEventSynchronize(c->ev_d2h[par(k)]));
+        if (out.jpeg) { // header + byte-stuffed segment + EOI for every plane of the batch
+            const unsigned char *hb = c->jpeg.h_stream[par(k)];
+            for (int j = 0; j < 2 * p.nb; ++j) {
+                const bool is_y = j >= p.nb;
+                const int i = p.i0 + (is_y ? j - p.nb : j);
+                const size_t n = jpeg_assemble(c->jpeg.header, hb + jb[k].base[j], jb[k].bits[j],
+                                               is_y ? out.jpg_y[i] : out.jpg_x[i], out.jpg_capacity);
+                if (n == 0)
+                    return dfx_fail(c, DFX_ERR_INVALID, "JPEG: jpg_capacity is too small for an encoded plane");
+                (is_y ? out.size_y : out.size_x)[i] = (uint32_t)n;
+            }
+            return DFX_OK;
+        }
         const unsigned char *hb = c->h_out[par(k)];
         for (int j = 0; j < p.nb; ++j) {
             if (out.quantized) {
@@ -463,8 +559,29 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             HIPCHK(c, hipGetLastError());
             c->stats.kernel_launches += 1;
         }
+        if (out.jpeg) { // imencode(".jpg") of both planes of every flow, on the device (src/common.cpp:56-57)
+            JpegCtx jc;
+            jc.planes = c->d_img[par(k)];
+            jc.plane_stride = (long long)plane;
+            jc.pitch = c->W, jc.w = c->W, jc.h = c->H, jc.bw = (c->W + 7) / 8, jc.bh = (c->H + 7) / 8;
+            jc.n_pairs = p.nb, jc.y_first = c->img_slots;
+            jc.tab = c->jpeg.d_tab, jc.dc = c->jpeg.d_dc, jc.bits = c->jpeg.d_bits;
+            jc.plane_bits = c->jpeg.d_plane_bits, jc.plane_base = c->jpeg.d_plane_base;
+            jc.stream = c->jpeg.d_stream[par(k)], jc.capacity_bytes = c->jpeg.capacity;
+            jc.info = c->jpeg.d_info[par(k)], jc.hdr = c->jpeg.d_hdr;
+            jpeg_launch_encode(c->stream, jc);
+            HIPCHK(c, hipGetLastError());
+            c->stats.kernel_launches += 5;
+        }
         HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_compute[par(k)], c->stream));
+        if ((bounce || out.jpeg) && k >= 1) {
+            // host work on the results of batch k-1 (hand the rows over / assemble the JPEG files) while batch k computes:
+            // its download was enqueued at the top of this iteration and is a fraction of a batch's compute time
+            rc = scatter(k - 1);
+            if (rc != DFX_OK)
+                return rc;
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream)); // the engines' statistics read-backs are complete
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
@@ -472,10 +589,13 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         rc = E->account(p.nb);
         if (rc != DFX_OK)
             return rc;
-        if (bounce && k >= 1) { // batch k-1 came down while batch k computed
-            rc = scatter(k - 1);
-            if (rc != DFX_OK)
-                return rc;
+        if (out.jpeg) { // the stream is idle: the totals of this batch are in the mapped block
+            const unsigned long long *hi = c->jpeg.h_info[par(k)];
+            jb[k].total = hi[0], jb[k].overflow = hi[1];
+            for (int j = 0; j < 2 * p.nb; ++j) {
+                jb[k].bits.push_back(hi[2 + 2 * j]);
+                jb[k].base.push_back(hi[2 + 2 * j + 1]);
+            }
         }
     }
     if (host_mode) {
@@ -506,6 +626,20 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             }
             const bool quant = out.quantized;
             const size_t dpitch = quant ? out.img_pitch : out.out_pitch;
+            // JPEG mode: the last batch's planes are assembled by the tail (header + stuffing is host work)
+            const bool jpeg = out.jpeg;
+            const unsigned char *jhb = jpeg ? c->jpeg.h_stream[par(last)] : nullptr;
+            const std::vector<unsigned char> jheader = jpeg ? c->jpeg.header : std::vector<unsigned char>();
+            const JpegBatch jlast = jpeg ? jb[last] : JpegBatch();
+            std::vector<unsigned char *> jdst;
+            std::vector<uint32_t *> jsize;
+            const size_t jcap = out.jpg_capacity;
+            for (int j = 0; jpeg && j < 2 * lp.nb; ++j) {
+                const bool is_y = j >= lp.nb;
+                const int i = lp.i0 + (is_y ? j - lp.nb : j);
+                jdst.push_back(is_y ? out.jpg_y[i] : out.jpg_x[i]);
+                jsize.push_back((is_y ? out.size_y : out.size_x) + i);
+            }
             std::mutex *mtx = &c->tails_mtx;
             std::condition_variable *cv = &c->tails_cv;
             t->worker = std::thread([=]() {
@@ -516,6 +650,15 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 if (e != hipSuccess) {
                     wrc = DFX_ERR_HIP;
                     werr = std::string("deferred download failed: ") + hipGetErrorString(e);
+                } else if (jpeg) {
+                    for (size_t j = 0; j < jdst.size(); ++j) {
+                        const size_t n = jpeg_assemble(jheader, jhb + jlast.base[j], jlast.bits[j], jdst[j], jcap);
+                        if (n == 0 && wrc == DFX_OK) {
+                            wrc = DFX_ERR_INVALID;
+                            werr = "JPEG: jpg_capacity is too small for an encoded plane";
+                        }
+                        *jsize[j] = (uint32_t)n;
+                    }
                 } else if (hb) {
                     const size_t pl = (size_t)W * H;
                     for (int j = 0; j < lp.nb; ++j) {
@@ -543,7 +686,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             return DFX_OK;
         }
         HIPCHK(c, hipStreamSynchronize(c->d2h_stream));
-        if (bounce) {
+        if (bounce || out.jpeg) {
             rc = scatter(last);
             if (rc != DFX_OK)
                 return rc;
@@ -799,6 +942,66 @@ int dfx_submit_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame
     return rc;
 }
 
+namespace {
+int jpeg_entry(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step, double lower_bound,
+               double upper_bound, int quality, uint8_t *const *jpg_x, uint8_t *const *jpg_y, size_t jpg_capacity,
+               uint32_t *size_x, uint32_t *size_y, uint64_t *ticket) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    const int M = std::max(n_frames - std::abs(step), 0);
+    if (M > 0 && (!frames || !jpg_x || !jpg_y || !size_x || !size_y))
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL frames, JPEG buffer or size array");
+    if (M > 0 && frame_pitch < h->in_row_bytes())
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
+    if (quality < 1 || quality > 100)
+        return dfx_fail(h, DFX_ERR_INVALID, "JPEG quality must be 1..100");
+    if (h->W > 65535 || h->H > 65535)
+        return dfx_fail(h, DFX_ERR_UNSUPPORTED, "JPEG: frame larger than 65535 pixels");
+    OutSpec out;
+    out.quantized = true;
+    out.jpeg = true;
+    out.lo = lower_bound;
+    out.hi = upper_bound;
+    out.quality = quality;
+    out.jpg_x = jpg_x;
+    out.jpg_y = jpg_y;
+    out.jpg_capacity = jpg_capacity;
+    out.size_x = size_x;
+    out.size_y = size_y;
+    unsigned long long t = 0;
+    const int rc = calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, out, ticket ? &t : nullptr);
+    if (ticket)
+        *ticket = t;
+    return rc;
+}
+} // namespace
+
+int dfx_calc_batch_jpeg(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
+                        double lower_bound, double upper_bound, int quality, uint8_t *const *jpg_x,
+                        uint8_t *const *jpg_y, size_t jpg_capacity, uint32_t *size_x, uint32_t *size_y) {
+    return jpeg_entry(h, frames, frame_pitch, n_frames, step, lower_bound, upper_bound, quality, jpg_x, jpg_y,
+                      jpg_capacity, size_x, size_y, nullptr);
+}
+
+int dfx_submit_batch_jpeg(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
+                          double lower_bound, double upper_bound, int quality, uint8_t *const *jpg_x,
+                          uint8_t *const *jpg_y, size_t jpg_capacity, uint32_t *size_x, uint32_t *size_y,
+                          uint64_t *ticket) {
+    if (h && !ticket)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL ticket");
+    return jpeg_entry(h, frames, frame_pitch, n_frames, step, lower_bound, upper_bound, quality, jpg_x, jpg_y,
+                      jpg_capacity, size_x, size_y, ticket);
+}
+
+size_t dfx_jpeg_capacity(dfx_handle h) {
+    if (!h)
+        return 0;
+    // header (623 bytes) + the entropy-coded segment.  A plane whose segment exceeds its pixel count (8 bits per pixel
+    // BEFORE stuffing) is far outside what flow images produce; such a FlowBuffer fails with DFX_ERR_INVALID /
+    // DFX_ERR_UNSUPPORTED and the caller encodes its 8-bit planes (dfx_calc_batch_u8) itself.
+    return (size_t)h->W * h->H + 4096;
+}
+
 int dfx_wait(dfx_handle h, uint64_t ticket) {
     if (!h)
         return DFX_ERR_INVALID;
@@ -987,6 +1190,7 @@ void dfx_destroy(dfx_handle h) {
         dfx_free_host(p);
     for (auto &p : h->h_out)
         dfx_free_host(p);
+    free_jpeg(h);
     for (auto &e : h->ev_h2d)
         if (e)
             (void)hipEventDestroy(e);

@@ -86,6 +86,21 @@ struct dfx_context {
     size_t h_in_bytes = 0, h_out_bytes = 0;
     unsigned char *d_img[2] = {nullptr, nullptr}; // bounded output: img_slots x planes, then img_slots y planes
     int img_slots = 0;
+    // device JPEG encoder (jpeg_kernels.hip): tables + per-block temporaries (one set, compute stream only), and per
+    // staging parity the shared stream buffer, its page-locked landing buffer and the totals the device reports
+    struct JpegState {
+        int quality = 0, pairs = 0; // what the buffers below are sized for
+        struct JpegTables *d_tab = nullptr;
+        short *d_dc = nullptr;
+        unsigned *d_bits = nullptr;
+        unsigned long long *d_plane_bits = nullptr, *d_plane_base = nullptr;
+        unsigned *d_stream[2] = {nullptr, nullptr};
+        unsigned char *h_stream[2] = {nullptr, nullptr};
+        unsigned long long *h_info[2] = {nullptr, nullptr}, *d_info[2] = {nullptr, nullptr}; // mapped page-locked
+        unsigned long long *d_hdr = nullptr; // device copy of (total, overflow): the emit pass must not poll host memory
+        size_t capacity = 0;
+        std::vector<unsigned char> header;
+    } jpeg;
     std::vector<int> h_slots;      // slot id of each new frame of the current batch
     std::vector<PairDesc> h_pairs; // descriptors of the current batch
 

@@ -164,6 +164,15 @@ def load_library():
     L.dfx_submit_batch_u8.argtypes = [vp, C.POINTER(vp), sz, i, i, C.c_double, C.c_double, C.POINTER(vp), C.POINTER(vp),
                                       sz, C.POINTER(C.c_uint64)]
     L.dfx_submit_batch_u8.restype = i
+    u32p = C.POINTER(C.c_uint32)
+    L.dfx_calc_batch_jpeg.argtypes = [vp, C.POINTER(vp), sz, i, i, C.c_double, C.c_double, i, C.POINTER(vp),
+                                      C.POINTER(vp), sz, u32p, u32p]
+    L.dfx_calc_batch_jpeg.restype = i
+    L.dfx_submit_batch_jpeg.argtypes = [vp, C.POINTER(vp), sz, i, i, C.c_double, C.c_double, i, C.POINTER(vp),
+                                        C.POINTER(vp), sz, u32p, u32p, C.POINTER(C.c_uint64)]
+    L.dfx_submit_batch_jpeg.restype = i
+    L.dfx_jpeg_capacity.argtypes = [vp]
+    L.dfx_jpeg_capacity.restype = sz
     L.dfx_wait.argtypes = [vp, C.c_uint64]
     L.dfx_wait.restype = i
     L.dfx_calc_batch_u8_device.argtypes = [vp, vp, sz, sz, i, i, C.c_double, C.c_double, vp, vp, sz, sz]
@@ -384,6 +393,27 @@ class FlowEngine:
         self._check(self._L.dfx_calc_batch_u8(self._h, fp, frames[0].strides[0], n, int(step), lo, float(bound), xp,
                                               yp, self.width))
         return img_x, img_y
+
+    def calc_optflows_jpeg(self, frames_gray, step: int, bound: float, quality: int = 95):
+        """encodeFlowMap of every flow of the FlowBuffer on the device (src/common.cpp:48-64): returns two lists of
+        `bytes`, the flow_x and flow_y JPEG files (bounded to [-bound, bound], quality like cv::imencode)."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
+        n = len(frames)
+        m = max(n - abs(step), 0)
+        if m == 0:
+            return [], []
+        for f in frames:
+            if f.shape != self._frame_shape():
+                raise ValueError("frame shape does not match the engine")
+        cap = int(self._L.dfx_jpeg_capacity(self._h))
+        bx = [np.empty(cap, np.uint8) for _ in range(m)]
+        by = [np.empty(cap, np.uint8) for _ in range(m)]
+        sx, sy = (C.c_uint32 * m)(), (C.c_uint32 * m)()
+        fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        self._check(self._L.dfx_calc_batch_jpeg(self._h, fp, frames[0].strides[0], n, int(step), -float(bound),
+                                                float(bound), int(quality), (C.c_void_p * m)(*[b.ctypes.data for b in bx]),
+                                                (C.c_void_p * m)(*[b.ctypes.data for b in by]), cap, sx, sy))
+        return ([bx[i][:sx[i]].tobytes() for i in range(m)], [by[i][:sy[i]].tobytes() for i in range(m)])
 
     def calc_optflows_u8_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,
                                 lower: float, upper: float, d_img_x_ptr: int, d_img_y_ptr: int, img_pitch: int,

@@ -30,6 +30,13 @@ class FlowBuffer {
     // Extension: flows already bounded to 8 bits on the device.  item_data then holds 2M CV_8UC1 planes,
     // x and y alternating (flow i = item_data[2i], item_data[2i+1]), instead of M CV_32FC2 fields.
     bool bounded;
+    // Extension: flows already ENCODED on the device (dfx_submit_batch_jpeg): complete JPEG files, item_data is empty.
+    // Plain (pageable, uninitialised) buffers: the library assembles the files on the host, nothing is DMA'd into them.
+    struct Encoded {
+        vector<std::unique_ptr<uchar[]>> x, y; // file i of flow_x / flow_y
+        vector<uint32_t> size_x, size_y;       // its size in bytes (valid once the FlowBuffer's ticket has been waited on)
+    };
+    std::shared_ptr<Encoded> encoded;
     // Extension: frames that still have the source size; the flow stage resizes them to `target` on the device
     // (width 0: the frames already have their final size).
     Size target;
@@ -78,6 +85,10 @@ class DenseFlow {
     // the reference's host-side convertFlowToImage.  encode_threads: JPEG/PNG encoders running in parallel
     // inside encode_save (the reference encodes on one thread); DF_ENCODE_THREADS overrides.
     bool device_bounding;
+    // device_jpeg: for save_type "jpg" the bounded planes are also JPEG-coded on the GPU (dfx_submit_batch_jpeg:
+    // encodeFlowMap as a whole, src/common.cpp:48-64); the save stage only writes files.  DF_HOST_JPEG=1 keeps the
+    // encoders on the host (device bounding only).
+    bool device_jpeg;
     int encode_threads;
     // Extension of the load stage: a requested resize (-nw/-nh/-ns) is done by the flow stage
     // on the GPU (dfx_set_source_format) instead of cv::resize on the loader thread; DF_HOST_RESIZE=1 restores

@@ -79,6 +79,7 @@ DenseFlow::DenseFlow(vector<path> video_paths, vector<path> output_dirs, string 
       new_short(new_short), has_class(has_class), is_record(is_record), device(device), batch_maxsize(512),
       frames_gray_queue(3), flows_queue(3), total_frames(0), total_flows(0), dfx_(nullptr) {
     device_bounding = this->save_type == "jpg" && !std::getenv("DF_HOST_BOUND");
+    device_jpeg = device_bounding && !std::getenv("DF_HOST_JPEG");
     device_resize = !std::getenv("DF_HOST_RESIZE");
     const char *et = std::getenv("DF_ENCODE_THREADS");
     int hw = (int)std::thread::hardware_concurrency();
@@ -399,6 +400,7 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
     const int M = std::max(N - std::abs(step), 0);
     vector<Mat> flows(M);
     uint64_t ticket = 0;
+    std::shared_ptr<FlowBuffer::Encoded> encoded;
     if (M > 0) {
         dfx_algo algo;
         const int rc = dfx_algo_from_name(algorithm.c_str(), &algo);
@@ -434,7 +436,34 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
         vector<const uint8_t *> in(N);
         for (int i = 0; i < N; ++i)
             in[i] = frames_gray.item_data[i].ptr<uint8_t>();
-        if (device_bounding) {
+        bool encoded_on_device = false;
+        if (device_jpeg) {
+            // encodeFlowMap as a whole (src/common.cpp:48-64) happens on the device: convertFlowToImage(-bound, bound)
+            // and both imencode(".jpg") — complete files come back, ~0.1 of the planes' bytes
+            const size_t cap = dfx_jpeg_capacity(dfx_);
+            encoded = std::make_shared<FlowBuffer::Encoded>();
+            encoded->size_x.assign(M, 0u), encoded->size_y.assign(M, 0u);
+            vector<uint8_t *> out_x(M), out_y(M);
+            for (int i = 0; i < M; ++i) {
+                encoded->x.emplace_back(new uchar[cap]);
+                encoded->y.emplace_back(new uchar[cap]);
+                out_x[i] = encoded->x[i].get();
+                out_y[i] = encoded->y[i].get();
+            }
+            const int jrc = dfx_submit_batch_jpeg(dfx_, in.data(), frames_gray.item_data[0].step, N, step, -bound, bound,
+                                                  95 /* cv::imencode's default quality */, out_x.data(), out_y.data(), cap,
+                                                  encoded->size_x.data(), encoded->size_y.data(), &ticket);
+            if (jrc == DFX_OK) {
+                flows.clear();
+                encoded_on_device = true;
+            } else if (jrc != DFX_ERR_UNSUPPORTED) { // UNSUPPORTED: planes that do not compress; encode them on the host
+                throw std::runtime_error(dfx_last_error(dfx_));
+            } else {
+                encoded.reset();
+            }
+        }
+        if (encoded_on_device) {
+        } else if (device_bounding) {
             // encodeFlowMap's convertFlowToImage(-bound, bound) (src/common.cpp:52) happens on the device:
             // two 8-bit planes per flow come back instead of a float field
             flows.resize(2 * (size_t)M);
@@ -465,10 +494,11 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
         cout << "flows queue push a item" << endl;
     // the collector thread waits for the tail (last download + hand-over) and pushes the flows to the save stage
     // while this thread already submits the next FlowBuffer
-    enqueue_pending(std::unique_ptr<PendingFlows>(
-        new PendingFlows{FlowBuffer(flows, frames_gray.output_dir, frames_gray.base_start, frames_gray.last_buffer,
-                                    device_bounding && M > 0),
-                         ticket, is_final, ticket ? dfx_ : nullptr}));
+    FlowBuffer result(flows, frames_gray.output_dir, frames_gray.base_start, frames_gray.last_buffer,
+                      device_bounding && M > 0);
+    result.encoded = encoded;
+    enqueue_pending(std::unique_ptr<PendingFlows>(new PendingFlows{std::move(result), ticket, is_final,
+                                                                   ticket ? dfx_ : nullptr}));
     // DF_SYNC_FLOW=1 (A/B measurements): collect every FlowBuffer at once, like the synchronous dfx_calc_batch*
     static const bool sync_flow = std::getenv("DF_SYNC_FLOW") != nullptr;
     if (sync_flow)
@@ -527,13 +557,20 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
     while (true) {
         bool is_final = false;
         FlowBuffer flow_buffer = flows_queue.pop(&is_final);
-        const int M = (int)flow_buffer.item_data.size() / (flow_buffer.bounded ? 2 : 1);
+        const int M = flow_buffer.encoded ? (int)flow_buffer.encoded->x.size()
+                                          : (int)flow_buffer.item_data.size() / (flow_buffer.bounded ? 2 : 1);
         TRACE("save: %d flows, base %d, final %d", M, flow_buffer.base_start, (int)is_final);
         // The flows of a buffer are independent: the encoders run encode_threads wide (one thread in the
         // reference, :414-437).  Files are still written in index order by this thread.
         if (save_type == "jpg") {
             vector<vector<uchar>> output_x(M), output_y(M);
-            if (flow_buffer.bounded) { // planes arrive bounded from the device: encode only
+            if (flow_buffer.encoded) { // complete JPEG files arrive from the device: nothing left to encode
+                const FlowBuffer::Encoded &e = *flow_buffer.encoded;
+                for (int i = 0; i < M; ++i) {
+                    output_x[i].assign(e.x[i].get(), e.x[i].get() + e.size_x[i]);
+                    output_y[i].assign(e.y[i].get(), e.y[i].get() + e.size_y[i]);
+                }
+            } else if (flow_buffer.bounded) { // planes arrive bounded from the device: encode only
                 parallelFor(2 * M, encode_threads, [&](int k) {
                     if (!imencodeJpeg(flow_buffer.item_data[k], (k & 1) ? output_y[k / 2] : output_x[k / 2]))
                         throw std::runtime_error("JPEG encoder failed");

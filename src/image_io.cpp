@@ -3,6 +3,8 @@
 // Host glue outside the hot path; nothing here runs on the GPU.
 #include "image_io.h"
 
+#include "dfx_jpeg_tables.h"
+
 #include <zlib.h>
 
 #if defined(__x86_64__)
@@ -186,26 +188,12 @@ void resizeLinear(const Mat &src, Mat &dst, Size size) {
 
 namespace {
 
-const uchar kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
-                           41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
-                           30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-const uchar kLumaQ[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,
-                          14, 13, 16, 24, 40,  57,  69,  56,  14, 17, 22, 29, 51,  87,  80,  62,
-                          18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
-                          49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
-const uchar kDcBits[17] = {0, 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
-const uchar kDcVal[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-const uchar kAcBits[17] = {0, 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
-const uchar kAcVal[162] = {
-    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71,
-    0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72,
-    0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
-    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
-    0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83,
-    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
-    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3,
-    0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
-    0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+// tables shared with the device encoder (include/dfx_jpeg_tables.h): both encoders must produce the same bytes
+const unsigned char (&kZigzag)[64] = kDfxJpegZigzag;
+const unsigned char (&kDcBits)[17] = kDfxJpegDcBits;
+const unsigned char (&kDcVal)[12] = kDfxJpegDcVal;
+const unsigned char (&kAcBits)[17] = kDfxJpegAcBits;
+const unsigned char (&kAcVal)[162] = kDfxJpegAcVal;
 
 struct HuffTable {
     unsigned short code[256];
@@ -266,19 +254,21 @@ void load_block(const uchar *src, size_t pitch, int valid_w, int valid_h, float 
 }
 
 void fdct_quant_portable(const float blk[8][8], const float (*c)[8], const float *rq, int *coef) {
+    // the very operations of the AVX2 form and of the device encoder: one product, then seven fused multiply-adds in
+    // index order (std::fmaf is exact whether or not the CPU has an FMA unit), so every path gives the same coefficients
     float t1[8][8]; // t1[v][x] = sum_y c[v][y] * blk[y][x]
     for (int v = 0; v < 8; ++v)
         for (int x = 0; x < 8; ++x) {
-            float s = 0;
-            for (int y = 0; y < 8; ++y)
-                s += c[v][y] * blk[y][x];
+            float s = c[v][0] * blk[0][x];
+            for (int y = 1; y < 8; ++y)
+                s = std::fmaf(c[v][y], blk[y][x], s);
             t1[v][x] = s;
         }
     for (int v = 0; v < 8; ++v)
         for (int u = 0; u < 8; ++u) {
-            float s = 0;
-            for (int x = 0; x < 8; ++x)
-                s += c[u][x] * t1[v][x];
+            float s = c[u][0] * t1[v][0];
+            for (int x = 1; x < 8; ++x)
+                s = std::fmaf(c[u][x], t1[v][x], s);
             coef[v * 8 + u] = (int)std::lrintf(s * rq[v * 8 + u]);
         }
 }
@@ -351,14 +341,11 @@ void imencodeJpegForcePortable(bool on) { g_force_portable = on; }
 bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
     if (gray.empty() || gray.type() != CV_8UC1)
         return false;
-    quality = std::min(100, std::max(1, quality));
-    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
     uchar q[64];
     float rq[64];
-    for (int i = 0; i < 64; ++i) {
-        q[i] = (uchar)std::min(255, std::max(1, (kLumaQ[i] * scale + 50) / 100));
+    dfx_jpeg_quantiser(quality, q);
+    for (int i = 0; i < 64; ++i)
         rq[i] = 1.0f / (float)q[i];
-    }
     struct Tables {
         HuffTable dc, ac;
         float c[8][8];      // c[u][x] = DCT-II basis, orthonormal
@@ -368,7 +355,7 @@ bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
             ac.build(kAcBits, kAcVal);
             for (int u = 0; u < 8; ++u)
                 for (int x = 0; x < 8; ++x)
-                    c[u][x] = (float)(std::cos((2 * x + 1) * u * M_PI / 16.0) * (u == 0 ? std::sqrt(0.125) : 0.5));
+                    c[u][x] = kDfxJpegDctBasis[u][x];
             for (int k = 0; k < 64; ++k)
                 nat2zig[kZigzag[k]] = (uchar)k;
         }

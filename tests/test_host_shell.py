@@ -294,7 +294,7 @@ def test_cli_device_bounding_writes_the_same_files_as_host_bounding(built, tmp_p
     lst = tmp_path / "list.txt"
     lst.write_text(str(clip) + "\n")
     outs = {}
-    for tag, env in (("dev", {}), ("host", {"DF_HOST_BOUND": "1", "DF_ENCODE_THREADS": "1"})):
+    for tag, env in (("dev", {"DF_HOST_JPEG": "1"}), ("host", {"DF_HOST_BOUND": "1", "DF_ENCODE_THREADS": "1"})):
         r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / tag), "-a=farn", "-s=2", "-b=8"],
                            capture_output=True, text=True, env={**os.environ, **env})
         assert r.returncode == 0, r.stdout + r.stderr
@@ -302,6 +302,33 @@ def test_cli_device_bounding_writes_the_same_files_as_host_bounding(built, tmp_p
         outs[tag] = {f: (tmp_path / tag / "clip" / f).read_bytes() for f in files}
     assert len(outs["dev"]) == 2 * (n - 2) and outs["dev"].keys() == outs["host"].keys()
     assert all(outs["dev"][f] == outs["host"][f] for f in outs["dev"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,algo,step", [(160, 120, "farn", 2), (227, 131, "tvl1", 1), (640, 360, "farn", -1)])
+def test_cli_device_jpeg_writes_the_same_files_as_the_host_encoders(built, tmp_path, w, h, algo, step):
+    """The default save path for -st=jpg: flows are bounded AND JPEG-coded on the GPU (dfx_submit_batch_jpeg), the save
+    stage only writes the files.  DF_HOST_JPEG=1 keeps the encoders on the host (device bounding only) and
+    DF_HOST_BOUND=1 is the reference's all-host encodeFlowMap: all three must write the same bytes — across several
+    short FlowBuffers (DF_BATCH_MAXSIZE) so that batches, tails and buffer reuse are all exercised."""
+    n = 9
+    frames = SynthClip(w, h, 14).frames(n)
+    clip = tmp_path / "clip.y4m"
+    write_y4m(clip, frames)
+    lst = tmp_path / "list.txt"
+    lst.write_text(str(clip) + "\n")
+    outs = {}
+    for tag, env in (("gpu_jpeg", {"DF_BATCH_MAXSIZE": "4"}), ("host_jpeg", {"DF_HOST_JPEG": "1"}),
+                     ("all_host", {"DF_HOST_BOUND": "1", "DF_ENCODE_THREADS": "2"})):
+        r = subprocess.run([built, str(lst), "-o=" + str(tmp_path / tag), "-a=" + algo, "-s=%d" % step, "-b=20"],
+                           capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+        files = sorted(p.name for p in (tmp_path / tag / "clip").iterdir())
+        outs[tag] = {f: (tmp_path / tag / "clip" / f).read_bytes() for f in files}
+    assert len(outs["gpu_jpeg"]) == 2 * (n - abs(step))
+    for other in ("host_jpeg", "all_host"):
+        assert outs["gpu_jpeg"].keys() == outs[other].keys()
+        assert all(outs["gpu_jpeg"][f] == outs[other][f] for f in outs["gpu_jpeg"]), other
 
 
 def _write_pgm_dir(d, frames):

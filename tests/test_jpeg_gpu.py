@@ -1,0 +1,100 @@
+"""Device JPEG encoder (denseflow_amd/csrc/jpeg_kernels.hip, dfx_calc_batch_jpeg): the files must be, byte for byte,
+what the shell's host encoder (src/image_io.cpp: imencodeJpeg — the stand-in for the reference's imencode(".jpg"),
+/root/reference/src/common.cpp:56-57) writes for the same bounded planes, and decode (PIL) to those planes within JPEG
+error.  Integer / byte work: bit-exact."""
+import ctypes as C
+import io
+
+import numpy as np
+import pytest
+
+from denseflow_amd.synth import SynthClip
+from tests.test_host_shell import built, harness  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_file(harness, plane, quality):
+    harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    h, w = plane.shape
+    buf = np.zeros(w * h * 3 + 4096, np.uint8)
+    plane = np.ascontiguousarray(plane)
+    n = harness.hh_encode_jpeg(plane.ctypes.data, w, h, quality, buf.ctypes.data, buf.size)
+    assert n > 0
+    return buf[:n].tobytes()
+
+
+@pytest.mark.parametrize("algo,w,h,n,quality,batch", [("farn", 640, 360, 6, 95, 2), ("farn", 70, 45, 4, 95, 0),
+                                                      ("tvl1", 224, 224, 5, 95, 3), ("farn", 257, 131, 4, 50, 0),
+                                                      ("farn", 64, 64, 3, 100, 0), ("brox", 352, 288, 3, 95, 0),
+                                                      ("farn", 1920, 1080, 4, 95, 2), ("farn", 33, 17, 3, 10, 0)])
+def test_files_are_the_host_encoders_byte_for_byte(dfx, harness, algo, w, h, n, quality, batch):
+    from PIL import Image
+
+    frames = SynthClip(w, h, 31).frames(n)
+    knobs = {"max_batch": batch} if batch else {}
+    with dfx.FlowEngine(w, h, algo, **knobs) as eng:
+        px, py = eng.calc_optflows_u8(frames, 1, 20)
+        jx, jy = eng.calc_optflows_jpeg(frames, 1, 20, quality)
+        jx2, jy2 = eng.calc_optflows_jpeg(frames, 1, 20, quality)  # buffers are reused across calls
+    assert len(jx) == len(px) == n - 1
+    for i in range(n - 1):
+        for plane, got, again in ((px[i], jx[i], jx2[i]), (py[i], jy[i], jy2[i])):
+            want = _host_file(harness, plane, quality)
+            assert got == want, f"{algo} {w}x{h} q{quality} flow {i}: {len(got)} vs {len(want)} bytes"
+            assert again == want
+            dec = np.array(Image.open(io.BytesIO(got)))
+            assert dec.shape == (h, w)
+            if quality >= 95:
+                assert np.abs(dec.astype(int) - plane.astype(int)).mean() < 1.5
+
+
+def test_arbitrary_planes_including_stuffing_and_long_zero_runs(dfx, harness):
+    """Planes that are NOT flows, pushed through the same kernels (frames whose flow saturates the bound give planes of
+    0 / 255 runs; noise frames give busy spectra): still the host encoder's bytes, or a clean DFX_ERR_UNSUPPORTED when a
+    batch does not compress below 4 bits per pixel."""
+    rng = np.random.default_rng(8)
+    w, h = 200, 120
+    frames = [rng.integers(0, 256, (h, w)).astype(np.uint8) for _ in range(4)]  # noise: Farneback flows are garbage
+    with dfx.FlowEngine(w, h, "farn") as eng:
+        px, py = eng.calc_optflows_u8(frames, 1, 0.05)  # tiny bound: almost everything saturates to 0 / 255
+        try:
+            jx, jy = eng.calc_optflows_jpeg(frames, 1, 0.05, 95)
+        except dfx.DfxError as e:
+            assert e.status == 4 and "4 bits per pixel" in str(e)
+            return
+    for i in range(3):
+        assert jx[i] == _host_file(harness, px[i], 95) and jy[i] == _host_file(harness, py[i], 95)
+
+
+def test_submit_form_and_capacity_error(dfx, harness):
+    L = dfx.load_library()
+    w, h, n = 320, 240, 5
+    frames = [np.ascontiguousarray(f) for f in SynthClip(w, h, 5).frames(n)]
+    m = n - 1
+    with dfx.FlowEngine(w, h, "farn", max_batch=2) as eng:
+        px, py = eng.calc_optflows_u8(frames, 1, 20)
+        cap = int(L.dfx_jpeg_capacity(eng._h))
+        fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        outs = []
+        for _ in range(2):  # two FlowBuffers in flight
+            bx = [np.zeros(cap, np.uint8) for _ in range(m)]
+            by = [np.zeros(cap, np.uint8) for _ in range(m)]
+            sx, sy, t = (C.c_uint32 * m)(), (C.c_uint32 * m)(), C.c_uint64(0)
+            rc = L.dfx_submit_batch_jpeg(eng._h, fp, w, n, 1, -20.0, 20.0, 95, (C.c_void_p * m)(*[b.ctypes.data for b in bx]),
+                                         (C.c_void_p * m)(*[b.ctypes.data for b in by]), cap, sx, sy, C.byref(t))
+            assert rc == 0, L.dfx_last_error(eng._h)
+            outs.append((bx, by, sx, sy, t.value))
+        for bx, by, sx, sy, t in outs:
+            assert L.dfx_wait(eng._h, t) == 0
+            for i in range(m):
+                assert bx[i][:sx[i]].tobytes() == _host_file(harness, px[i], 95)
+                assert by[i][:sy[i]].tobytes() == _host_file(harness, py[i], 95)
+        # a capacity that cannot hold the file is an error, not a truncated file
+        small = 700
+        bx = [np.zeros(small, np.uint8) for _ in range(m)]
+        by = [np.zeros(small, np.uint8) for _ in range(m)]
+        sx, sy = (C.c_uint32 * m)(), (C.c_uint32 * m)()
+        rc = L.dfx_calc_batch_jpeg(eng._h, fp, w, n, 1, -20.0, 20.0, 95, (C.c_void_p * m)(*[b.ctypes.data for b in bx]),
+                                   (C.c_void_p * m)(*[b.ctypes.data for b in by]), small, sx, sy)
+        assert rc == 1 and b"jpg_capacity" in L.dfx_last_error(eng._h)

@@ -1,0 +1,82 @@
+"""The host half of the device JPEG encoder (denseflow_amd/csrc/jpeg_host.cpp), without a GPU: file header and byte
+stuffing must reproduce the shell's host encoder (src/image_io.cpp, imencodeJpeg) exactly.  A file written by the host
+encoder is split into header / entropy-coded segment, the segment is un-stuffed into the plain bit string the device
+produces, and dfxi_jpeg_assemble must rebuild the very same file from it."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.test_host_shell import built, harness  # noqa: F401  (fixtures)
+
+
+def _unstuff(seg: bytes):
+    out = bytearray()
+    i = 0
+    while i < len(seg):
+        out.append(seg[i])
+        if seg[i] == 0xFF:
+            assert seg[i + 1] == 0x00
+            i += 1
+        i += 1
+    return bytes(out)
+
+
+@pytest.mark.parametrize("w,h,quality", [(64, 48, 95), (70, 45, 95), (8, 8, 50), (257, 131, 100), (5, 3, 10), (640, 360, 95)])
+def test_assembly_reproduces_the_host_encoders_file(harness, w, h, quality):
+    import denseflow_amd
+
+    L = denseflow_amd.load_library()
+    L.dfxi_jpeg_assemble.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_ulonglong, C.c_void_p, C.c_size_t]
+    L.dfxi_jpeg_assemble.restype = C.c_size_t
+    harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(w + h + quality)
+    yy, xx = np.mgrid[0:h, 0:w]
+    # smooth + noise, and a saturated corner: runs of 0xFF bytes in the segment exercise the stuffing
+    gray = np.clip(128 + 90 * np.sin(xx / 11.0) * np.cos(yy / 5.0) + rng.normal(0, 25, (h, w)), 0, 255).astype(np.uint8)
+    gray[: h // 3, : w // 3] = 255
+    buf = np.zeros(4 << 20, np.uint8)
+    n = harness.hh_encode_jpeg(gray.ctypes.data, w, h, quality, buf.ctypes.data, buf.size)
+    assert n > 0
+    ref = buf[:n].tobytes()
+    sos = ref.index(b"\xff\xda")
+    header_len = sos + 2 + 8
+    assert ref.endswith(b"\xff\xd9")
+    plain = _unstuff(ref[header_len:-2])
+    # the host encoder pads the last byte with ones; the device reports the exact bit count.  Try every possible
+    # count that ends in this byte: the right one reproduces the file (the padding bits are ones either way)
+    ok = False
+    for pad in range(8):
+        bits = len(plain) * 8 - pad
+        seg = bytearray(plain)
+        if pad:
+            if seg[-1] & ((1 << pad) - 1) != (1 << pad) - 1:
+                continue
+            seg[-1] &= 0xFF ^ ((1 << pad) - 1)  # the device leaves the unused bits zero
+        seg = bytes(seg)
+        out = np.zeros(n + 64, np.uint8)
+        m = L.dfxi_jpeg_assemble(w, h, quality, seg, bits, out.ctypes.data, out.size)
+        if m == n and out[:m].tobytes() == ref:
+            ok = True
+            break
+    assert ok, "no bit count reproduces the host encoder's file"
+    # capacity check: one byte too few is refused
+    out = np.zeros(n - 1, np.uint8)
+    assert L.dfxi_jpeg_assemble(w, h, quality, seg, bits, out.ctypes.data, out.size) == 0
+
+
+def test_simd_and_portable_transforms_are_now_bit_identical(harness):
+    """Both host transforms and the device kernel evaluate one product and seven fused multiply-adds per output in the
+    same order (std::fmaf where there is no FMA unit): the files must be IDENTICAL, not just close."""
+    harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    rng = np.random.default_rng(4)
+    for (w, h) in [(64, 64), (70, 45), (257, 131), (9, 17)]:
+        gray = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        files = []
+        for portable in (0, 1):
+            harness.hh_jpeg_force_portable(portable)
+            buf = np.zeros(1 << 20, np.uint8)
+            n = harness.hh_encode_jpeg(gray.ctypes.data, w, h, 95, buf.ctypes.data, buf.size)
+            files.append(buf[:n].tobytes())
+        harness.hh_jpeg_force_portable(0)
+        assert files[0] == files[1], (w, h)
