@@ -20,7 +20,7 @@ _LIB_DIR = os.path.join(_HERE, "lib")
 _LIB = os.path.join(_LIB_DIR, "libdfx.so")
 _CSRC = os.path.join(_HERE, "csrc")
 
-DFX_MAX_LEVELS = 16
+DFX_MAX_LEVELS = 32
 DFX_MAX_WARPS = 16
 
 ALGO_TVL1, ALGO_FARN, ALGO_BROX = 0, 1, 2

@@ -704,6 +704,7 @@ void DenseFlow::launch(bool use_frames, string save_type, bool verbose) {
 vector<Mat> DenseFlowTestAccess::run_calc_optflows_imp(DenseFlow &d, const vector<Mat> &frames_gray,
                                                         const string &algorithm, int step, bool bounded) {
     d.device_bounding = bounded;
+    d.device_jpeg = false; // this probe returns flows / bounded planes; the encoded form is tested through the CLI
     d.flows_final_ = true;
     thread collector([&d] { d.collect_flows(); });
     std::exception_ptr err;

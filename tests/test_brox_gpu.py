@@ -71,7 +71,7 @@ def test_large_pyramid_1080p(dfx, oracle):
     with dfx.FlowEngine(w, h, "brox", max_batch=2) as eng:
         out = eng.calc(f0, f1)
         st = eng.stats()
-    assert st.levels == min(len(oracle.brox_pyramid_sizes(w, h)), 16)
+    assert st.levels == len(oracle.brox_pyramid_sizes(w, h)) == 21
     ref = oracle.brox_calc(f0, f1)
     assert np.max(np.abs(out - ref)) <= TOL
     gt = clip.true_flow(0, 2)
@@ -113,7 +113,8 @@ def test_config5_shape_4k_step2(dfx, oracle):
         st = eng.stats()
     assert len(flows) == n - 2
     sizes = oracle.brox_pyramid_sizes(w, h)
-    assert len(sizes) == 24 and st.levels == min(len(sizes), 16)
+    assert len(sizes) == 24 and st.levels == 24
+    assert [(st.level_w[l], st.level_h[l]) for l in range(24)] == [tuple(sz) for sz in sizes]
     for i in range(n - 2):
         ref = oracle.brox_calc(frames[i], frames[i + 2])
         assert np.max(np.abs(flows[i] - ref)) <= TOL, i
