@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 
 #include "dfx_internal.h"
 #include "jpeg_kernels.h"
@@ -490,6 +491,23 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         if (rc != DFX_OK)
             return rc;
     }
+    // helper thread for the host-side post-processing of the previous batch; joined on every path out of this function
+    struct Post {
+        std::thread th;
+        int rc = DFX_OK;
+        void start(std::function<int()> fn) {
+            (void)finish();
+            th = std::thread([this, fn] { rc = fn(); });
+        }
+        int finish() {
+            if (th.joinable())
+                th.join();
+            const int r = rc;
+            rc = DFX_OK;
+            return r;
+        }
+        ~Post() { (void)finish(); }
+    } post;
     for (size_t k = 0; k < plan.size(); ++k) {
         const BatchPlan &p = plan[k];
         if (host_mode) {
@@ -504,6 +522,15 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 rc = upload(k + 1);
                 if (rc != DFX_OK)
                     return rc;
+            }
+            if ((bounce || out.jpeg) && k >= 1) {
+                // host work on the results of batch k-1 (hand the rows over / assemble the JPEG files) on a helper thread
+                // while this thread drives batch k (the TVL1 engine polls the device inside run_pairs): its download was
+                // enqueued just above and is a fraction of a batch's compute time
+                post.start([&, k] {
+                    (void)hipSetDevice(c->device);
+                    return scatter(k - 1);
+                });
             }
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d[par(k)], 0));
             if (seq0 + k >= 2) // flow staging set par(k) must have been drained by the download of batch q-2
@@ -575,18 +602,14 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         }
         HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_compute[par(k)], c->stream));
-        if ((bounce || out.jpeg) && k >= 1) {
-            // host work on the results of batch k-1 (hand the rows over / assemble the JPEG files) while batch k computes:
-            // its download was enqueued at the top of this iteration and is a fraction of a batch's compute time
-            rc = scatter(k - 1);
-            if (rc != DFX_OK)
-                return rc;
-        }
         HIPCHK(c, hipStreamSynchronize(c->stream)); // the engines' statistics read-backs are complete
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
         c->stats.device_ms += ms;
         rc = E->account(p.nb);
+        if (rc != DFX_OK)
+            return rc;
+        rc = post.finish(); // batch k-1 is in the caller's buffers
         if (rc != DFX_OK)
             return rc;
         if (out.jpeg) { // the stream is idle: the totals of this batch are in the mapped block

@@ -45,6 +45,8 @@ extra = os.environ.get("EXTRA_ARGS", "").split()  # e.g. EXTRA_ARGS="-nw=224 -nh
 configs = [("ref-like", {"DF_HOST_BOUND": "1", "DF_ENCODE_THREADS": "1", "DF_HOST_RESIZE": "1"}),
            ("host-par", {"DF_HOST_BOUND": "1", "DF_HOST_RESIZE": "1"}), ("dev-bound/host-jpeg", {"DF_HOST_JPEG": "1"}),
            ("device", {})]
+if os.environ.get("CONFIGS"):  # e.g. CONFIGS="dev-bound/host-jpeg,device": long clips without the slow reference-like runs
+    configs = [c for c in configs if c[0] in os.environ["CONFIGS"].split(",")]
 if extra:
     configs.insert(2, ("dev-bound/host-resize", {"DF_HOST_RESIZE": "1", "DF_HOST_JPEG": "1"}))
 print(f"{NCLIPS} clip(s) {W}x{H} x {NF} frames, host cores {os.cpu_count()}", flush=True)
