@@ -100,6 +100,7 @@ void encodeFlowMapPng(const Mat &flow_map_x, const Mat &flow_map_y, vector<uchar
 void writeImages(vector<vector<uchar>> images, string name_prefix, const int start = 0);
 void writeFlowImages(vector<vector<uchar>> images, string name_prefix, const int step = 1, const int start = 0);
 void writeFlowImagesPng(vector<vector<uchar>> images, string name_prefix, const int step, const int start);
+void writeFlowImageBytes(const uchar *bytes, size_t size, const string &name_prefix, int step, int index);
 // -st=h5: reference src/common.cpp:121-149 (writeHDF5) and src/denseflow_gpu.cpp:223-243 (file creation); written
 // by src/h5mini.cpp without libhdf5
 string h5FileName(const string &name_prefix, int step);

@@ -37,6 +37,10 @@ class FlowBuffer {
         vector<uint32_t> size_x, size_y;       // its size in bytes (valid once the FlowBuffer's ticket has been waited on)
     };
     std::shared_ptr<Encoded> encoded;
+    // Extension: not a buffer of frames but the loader's early notice of the size the next video's flows will have
+    // (width > 0): the flow stage creates its engine (device allocations, ~0.3 s at 1080p) while the loader reads the
+    // first frames instead of after them.  Nothing is forwarded to the save stage.
+    Size engine_hint;
     // Extension: frames that still have the source size; the flow stage resizes them to `target` on the device
     // (width 0: the frames already have their final size).
     Size target;
@@ -96,6 +100,7 @@ class DenseFlow {
     bool device_resize;
 
     int batch_maxsize;
+    bool first_buffer_ = false; // the next FlowBuffer is the first of its video: a quarter of batch_maxsize
     // Level-2 sharding: this pipeline computes flows [begin, end) of every video, the contiguous
     // range of shard `shard_rank` of `shard_world`; output indices stay global through base_start.  Frames
     // [begin, end + |step|) are loaded — the |step| overlap frames the reference's own batch padding duplicates
@@ -142,6 +147,7 @@ class DenseFlow {
     void calc_optflows_imp(const FlowBuffer &frames_gray, const string &algorithm, int step, bool verbose,
                            Stream &stream = Stream::Null());
     void flush_pending();
+    void prepare_engine(const string &algorithm, const Size &sz);
     void load_frames(bool use_frames, string save_type, bool verbose = true);
     void calc_optflows(bool verbose = true);
     void encode_save(string save_type, bool verbose = true);

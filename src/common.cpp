@@ -219,6 +219,17 @@ void writeFlowImages(vector<vector<uchar>> images, string name_prefix, const int
         write_blob(name_prefix + flow_suffix(step, start + (int)i, ".jpg"), images[i]);
 }
 
+// One flow image whose bytes already exist (the device JPEG encoder's files): same naming as writeFlowImages, no copy.
+void writeFlowImageBytes(const uchar *bytes, size_t size, const string &name_prefix, int step, int index) {
+    const string file = name_prefix + flow_suffix(step, index, ".jpg");
+    FILE *fp = fopen(file.c_str(), "wb");
+    if (!fp)
+        throw std::runtime_error("cannot write " + file);
+    const size_t n = fwrite(bytes, 1, size, fp);
+    if (fclose(fp) != 0 || n != size)
+        throw std::runtime_error("cannot write " + file);
+}
+
 void writeFlowImagesPng(vector<vector<uchar>> images, string name_prefix, const int step, const int start) {
     for (size_t i = 0; i < images.size(); ++i)
         write_blob(name_prefix + flow_suffix(step, start + (int)i, ".png"), images[i]);

@@ -189,7 +189,9 @@ bool DenseFlow::load_frames_batch(VideoCapture &video_stream, const vector<path>
                                   vector<Mat> &frames_gray, bool do_resize, const Size &size, bool to_gray) {
     // to_gray: the flow pipeline (sources are gray already: Y plane / PGM / BGR2GRAY in imreadGray); false: -s=0
     int cnt = 0;
-    while (cnt < batch_maxsize) {
+    const int limit = first_buffer_ ? std::max(std::min(32, batch_maxsize), batch_maxsize / 4) : batch_maxsize;
+    first_buffer_ = false;
+    while (cnt < limit) {
         Mat frame;
         if (frames_budget == 0) // this pipeline's shard of the video ends here
             return false;
@@ -299,16 +301,26 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
             else if (!video_stream.seekFrame(fb))
                 throw std::runtime_error("cannot seek in " + video_path.string());
         }
-        // Frames per FlowBuffer.  The reference fixes 512 (include/dense_flow.h:33); the three stages only
-        // overlap across buffers, so large frames get shorter buffers (2 device batches each): 128 frames at
-        // 1080p, 512 from 724x724 down.  Buffer boundaries do not change any flow (the last |step| frames
-        // are carried over, :204-207).
+        // Frames per FlowBuffer.  The reference fixes 512 (include/dense_flow.h:33).  Here a buffer of large frames is
+        // TWO FULL device batches (the engine advances min(512, 256 Mi / pixels) pairs together: 129 at 1080p, where a
+        // batch of 64 runs 4 % slower): 258 frames at 1080p, 512 from 1024x1024 down — with -st=jpg the results are JPEG
+        // files or 8-bit planes, so a buffer's memory is its frames.  The three stages only overlap across buffers, so the
+        // FIRST buffer of a video is a quarter of that (the GPU starts after 64 frames, not 258).  Buffer boundaries
+        // do not change any flow (the last |step| frames are carried over, :204-207).
         const long long frame_px = std::max((long long)size.width * size.height, (long long)src_w_ * src_h_);
-        batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, (256ll << 20) / std::max(1ll, frame_px)));
+        // (float flows — png / h5 / host-side bounding — are 8 bytes per pixel of page-locked output per pair: one batch)
+        const long long budget = device_bounding ? (512ll << 20) : (256ll << 20);
+        batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, budget / std::max(1ll, frame_px)));
+        first_buffer_ = frame_px * batch_maxsize > (128ll << 20); // only where reading a full buffer takes a while
         if (const char *bm = std::getenv("DF_BATCH_MAXSIZE")) // testing aid: force short buffers
             batch_maxsize = std::max(1, std::atoi(bm));
         if (verbose)
             cout << video_path << ", frames ≈ " << frames_num << endl;
+        {   // early notice of the flows' size: the flow stage creates its engine while the first buffer is being read
+            FlowBuffer hint({}, path(), 0, false);
+            hint.engine_hint = size;
+            frames_gray_queue.push(std::move(hint), false);
+        }
         const bool is_last = i == video_paths.size() - 1;
         frames_num = load_frames_video(video_stream, frames_path, use_frames, do_resize, size, output_dir, is_last,
                                        verbose);
@@ -388,6 +400,26 @@ void DenseFlow::enqueue_pending(std::unique_ptr<PendingFlows> p) {
     pending_cv_.notify_all();
 }
 
+// The engine for flows of size sz (reference: the create() calls of :299-303, per FlowBuffer there).
+void DenseFlow::prepare_engine(const string &algorithm, const Size &sz) {
+    dfx_algo algo;
+    const int rc = dfx_algo_from_name(algorithm.c_str(), &algo);
+    if (rc != DFX_OK) { // "NV hardware flow not enabled, pls recompile" / "unknown optical algorithm <a>"
+        char msg[256];
+        throw std::runtime_error(dfx_algo_error_message(rc, algorithm.c_str(), msg, sizeof msg));
+    }
+    if (dfx_ && sz == dfx_size_)
+        return;
+    flush_pending();
+    if (dfx_)
+        dfx_destroy(dfx_);
+    dfx_ = nullptr;
+    if (dfx_create(&dfx_, device, algo, sz.width, sz.height, nullptr) != DFX_OK)
+        throw std::runtime_error(dfx_last_error(nullptr));
+    dfx_size_ = sz;
+    TRACE("calc: engine for %dx%d ready", sz.width, sz.height);
+}
+
 // One FlowBuffer of gray frames -> M = max(N - |step|, 0) flows, on the GPU (reference :282-370).  The `stream`
 // argument is the reference's (include/dense_flow.h:58-59); the engine owns its HIP streams, so it is only a tag here.
 // The FlowBuffer is SUBMITTED: its last download overlaps the next FlowBuffer's uploads and compute, and its flows are
@@ -402,12 +434,6 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
     uint64_t ticket = 0;
     std::shared_ptr<FlowBuffer::Encoded> encoded;
     if (M > 0) {
-        dfx_algo algo;
-        const int rc = dfx_algo_from_name(algorithm.c_str(), &algo);
-        if (rc != DFX_OK) { // "NV hardware flow not enabled, pls recompile" / "unknown optical algorithm <a>"
-            char msg[256];
-            throw std::runtime_error(dfx_algo_error_message(rc, algorithm.c_str(), msg, sizeof msg));
-        }
         const Size in_sz = frames_gray.item_data[0].size();
         const Size sz = frames_gray.target.width > 0 ? frames_gray.target : in_sz; // size of the flows
         // One pitch and one source format describe the whole FlowBuffer: every frame must have the first one's
@@ -421,15 +447,7 @@ void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &a
                                          std::to_string(in_sz.height) + ")");
         }
         TRACE("calc: %d frames -> %d flows, %dx%d, algorithm %s", N, M, sz.width, sz.height, algorithm.c_str());
-        if (!dfx_ || !(sz == dfx_size_)) { // sized per video; reused across its FlowBuffers
-            flush_pending();
-            if (dfx_)
-                dfx_destroy(dfx_);
-            dfx_ = nullptr;
-            if (dfx_create(&dfx_, device, algo, sz.width, sz.height, nullptr) != DFX_OK)
-                throw std::runtime_error(dfx_last_error(nullptr));
-            dfx_size_ = sz;
-        }
+        prepare_engine(algorithm, sz); // sized per video; reused across its FlowBuffers (usually created already: engine_hint)
         // cv::resize of load_frames_batch (:169) on the device: source-size frames go up, the engine resizes
         if (dfx_set_source_format(dfx_, sz == in_sz ? 0 : in_sz.width, sz == in_sz ? 0 : in_sz.height, 1) != DFX_OK)
             throw std::runtime_error(dfx_last_error(dfx_));
@@ -517,6 +535,10 @@ void DenseFlow::calc_optflows(bool verbose) {
             bool is_final = false;
             FlowBuffer frames_gray = frames_gray_queue.pop(&is_final);
             flows_final_ = is_final;
+            if (frames_gray.engine_hint.width > 0) { // the loader's early notice: allocate while it reads the first frames
+                prepare_engine(algorithm, frames_gray.engine_hint);
+                continue;
+            }
             calc_optflows_imp(frames_gray, algorithm, step, false, stream);
             if (is_final)
                 break;
@@ -562,15 +584,23 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
         TRACE("save: %d flows, base %d, final %d", M, flow_buffer.base_start, (int)is_final);
         // The flows of a buffer are independent: the encoders run encode_threads wide (one thread in the
         // reference, :414-437).  Files are still written in index order by this thread.
-        if (save_type == "jpg") {
+        if (save_type == "jpg" && flow_buffer.encoded) {
+            // complete JPEG files arrive from the device: nothing left to encode, and nothing to copy — the files are
+            // written straight from the buffers, a few writers wide (a 224x224 clip is 598 files of ~6 KB: the
+            // open / write / close of one file at a time was the save stage's whole cost there)
+            const FlowBuffer::Encoded &e = *flow_buffer.encoded;
+            const string px = (flow_buffer.output_dir / "flow_x").string(), py = (flow_buffer.output_dir / "flow_y").string();
+            parallelFor(2 * M, std::min(encode_threads, 8), [&](int k) {
+                const int i = k >> 1;
+                if (k & 1)
+                    writeFlowImageBytes(e.y[i].get(), e.size_y[i], py, step, flow_buffer.base_start + i);
+                else
+                    writeFlowImageBytes(e.x[i].get(), e.size_x[i], px, step, flow_buffer.base_start + i);
+            });
+            TRACE("save: written");
+        } else if (save_type == "jpg") {
             vector<vector<uchar>> output_x(M), output_y(M);
-            if (flow_buffer.encoded) { // complete JPEG files arrive from the device: nothing left to encode
-                const FlowBuffer::Encoded &e = *flow_buffer.encoded;
-                for (int i = 0; i < M; ++i) {
-                    output_x[i].assign(e.x[i].get(), e.x[i].get() + e.size_x[i]);
-                    output_y[i].assign(e.y[i].get(), e.y[i].get() + e.size_y[i]);
-                }
-            } else if (flow_buffer.bounded) { // planes arrive bounded from the device: encode only
+            if (flow_buffer.bounded) { // planes arrive bounded from the device: encode only
                 parallelFor(2 * M, encode_threads, [&](int k) {
                     if (!imencodeJpeg(flow_buffer.item_data[k], (k & 1) ? output_y[k / 2] : output_x[k / 2]))
                         throw std::runtime_error("JPEG encoder failed");
