@@ -121,8 +121,8 @@ __global__ __launch_bounds__(256) void k_brox_level_init(BroxLevelCtx c, int uv_
     }
 }
 
-struct BlTap {
-    long long i00, i01, i10, i11;
+struct BlTap { // 32-bit element offsets inside a level's plane (< 2^23 even at 3840x2160): the loads take the plane's
+    unsigned i00, i01, i10, i11; // uniform base pointer in scalar registers + zero-extended 32-bit lane offset: no 64-bit address math
     float ax, ay;
 };
 __device__ __forceinline__ BlTap bl_setup(float fx, float fy, int w, int h, int pitch) {
@@ -134,16 +134,23 @@ __device__ __forceinline__ BlTap bl_setup(float fx, float fy, int w, int h, int 
     t.ay = fy - y0;
     const int xa = mirror_idx((int)x0, w), xb = mirror_idx((int)x0 + 1, w);
     const int ya = mirror_idx((int)y0, h), yb = mirror_idx((int)y0 + 1, h);
-    t.i00 = (long long)ya * pitch + xa;
-    t.i01 = (long long)ya * pitch + xb;
-    t.i10 = (long long)yb * pitch + xa;
-    t.i11 = (long long)yb * pitch + xb;
+    t.i00 = (unsigned)(ya * pitch + xa);
+    t.i01 = (unsigned)(ya * pitch + xb);
+    t.i10 = (unsigned)(yb * pitch + xa);
+    t.i11 = (unsigned)(yb * pitch + xb);
     return t;
 }
 __device__ __forceinline__ float bl_sample(const float *p, const BlTap &t) {
     const float a = (1.0f - t.ax) * p[t.i00] + t.ax * p[t.i01];
     const float b = (1.0f - t.ax) * p[t.i10] + t.ax * p[t.i11];
     return (1.0f - t.ay) * a + t.ay * b;
+}
+// two planes at once: the same three rounded operations per half (v_pk_mul / v_pk_add), same bits as bl_sample
+__device__ __forceinline__ f2 bl_sample2(const float *p, const float *q, const BlTap &t) {
+    const f2 wx0 = (f2)(1.0f - t.ax), wx1 = (f2)(t.ax), wy0 = (f2)(1.0f - t.ay), wy1 = (f2)(t.ay);
+    const f2 a = wx0 * pk_set(p[t.i00], q[t.i00]) + wx1 * pk_set(p[t.i01], q[t.i01]);
+    const f2 b = wx0 * pk_set(p[t.i10], q[t.i10]) + wx1 * pk_set(p[t.i11], q[t.i11]);
+    return wy0 * a + wy1 * b;
 }
 
 // stage 1: data-term coefficients and staggered diffusivities (brox_oracle.h, step 3b).
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set,
     const float *DU = bplane(c, b, du_plane(d_set)), *DV = bplane(c, b, dv_plane(d_set));
     for (int e = threadIdx.x; e < 6 * 66; e += 256) {
         const int ty = e / 66, tx = e - ty * 66;
-        const long long so = (long long)min(max(y0 - 1 + ty, 0), h - 1) * pitch + min(max(x0 - 1 + tx, 0), w - 1);
+        const unsigned so = (unsigned)(min(max(y0 - 1 + ty, 0), h - 1) * pitch + min(max(x0 - 1 + tx, 0), w - 1));
         WUs[ty][tx] = u[so] + DU[so];
         WVs[ty][tx] = v[so] + DV[so];
     }
@@ -169,17 +176,15 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set,
     if (x >= w || y >= h)
         return;
     const PairDesc pd = c.pairs[b];
-    const long long o = (long long)y * pitch + x;
+    const unsigned o = (unsigned)(y * pitch + x); // 32-bit element offset inside the level's plane
     // tile coordinates of (x, y) are (lx + 1, ly + 1); m / p = the clamped neighbours
 #define WU(dx, dy) WUs[ly + 1 + (dy)][lx + 1 + (dx)]
 #define WV(dx, dy) WVs[ly + 1 + (dy)][lx + 1 + (dx)]
     const BlTap t = bl_setup((float)x + u[o], (float)y + v[o], w, h, pitch);
-    const float I1w = bl_sample(fplane(c, pd.frame_b, BROX_FP_I), t);
-    const float Ixw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DX), t);
-    const float Iyw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DY), t);
-    const float Ixxw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DXX), t);
-    const float Ixyw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DXY), t);
-    const float Iyyw = bl_sample(fplane(c, pd.frame_b, BROX_FP_DYY), t);
+    const f2 s01 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_I), fplane(c, pd.frame_b, BROX_FP_DX), t);
+    const f2 s23 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_DY), fplane(c, pd.frame_b, BROX_FP_DXX), t);
+    const f2 s45 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_DXY), fplane(c, pd.frame_b, BROX_FP_DYY), t);
+    const float I1w = s01.x, Ixw = s01.y, Iyw = s23.x, Ixxw = s23.y, Ixyw = s45.x, Iyyw = s45.y;
     const float Iz = I1w - fplane(c, pd.frame_a, BROX_FP_I)[o];
     const float Ixz = Ixw - fplane(c, pd.frame_a, BROX_FP_DX)[o];
     const float Iyz = Iyw - fplane(c, pd.frame_a, BROX_FP_DY)[o];

@@ -586,17 +586,15 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
         // reference, :414-437).  Files are still written in index order by this thread.
         if (save_type == "jpg" && flow_buffer.encoded) {
             // complete JPEG files arrive from the device: nothing left to encode, and nothing to copy — the files are
-            // written straight from the buffers, a few writers wide (a 224x224 clip is 598 files of ~6 KB: the
-            // open / write / close of one file at a time was the save stage's whole cost there)
+            // written straight from the buffers.  (Eight writers instead of one were measured: no faster within the
+            // run-to-run noise on a list of 224x224 clips, and twice the CPU time — 6.3 instead of 3.1 ms per 1080p
+            // pair, the threads contend inside the file system: profiles/round3/experiments/e2e_parallel_writers.log.)
             const FlowBuffer::Encoded &e = *flow_buffer.encoded;
             const string px = (flow_buffer.output_dir / "flow_x").string(), py = (flow_buffer.output_dir / "flow_y").string();
-            parallelFor(2 * M, std::min(encode_threads, 8), [&](int k) {
-                const int i = k >> 1;
-                if (k & 1)
-                    writeFlowImageBytes(e.y[i].get(), e.size_y[i], py, step, flow_buffer.base_start + i);
-                else
-                    writeFlowImageBytes(e.x[i].get(), e.size_x[i], px, step, flow_buffer.base_start + i);
-            });
+            for (int i = 0; i < M; ++i)
+                writeFlowImageBytes(e.x[i].get(), e.size_x[i], px, step, flow_buffer.base_start + i);
+            for (int i = 0; i < M; ++i)
+                writeFlowImageBytes(e.y[i].get(), e.size_y[i], py, step, flow_buffer.base_start + i);
             TRACE("save: written");
         } else if (save_type == "jpg") {
             vector<vector<uchar>> output_x(M), output_y(M);
