@@ -137,10 +137,16 @@ def load_library():
         return _lib
     if not os.path.exists(_LIB):
         raise DfxError(ERR_NO_DEVICE, f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    try:  # torch bundles its own libamdhip64.so; loading it first makes the loader reuse that copy
-        import torch  # noqa: F401
-    except Exception:  # pragma: no cover - torch is optional for the library itself
-        pass
+    # torch bundles its own libamdhip64.so (HIP 7.0 in torch 2.10+rocm7.0); importing it first makes the loader reuse that
+    # copy, which a process that also holds torch tensors needs (one runtime per process).  A torch-free process
+    # (DFX_NO_TORCH=1: binding-level switch, the library itself reads no environment) gets the system runtime libdfx.so
+    # was linked against (/opt/rocm, HIP 7.2) — what a C++ caller such as build/denseflow runs on.  The two runtimes differ
+    # in how they execute device-to-host copies (shader blit vs SDMA: DESIGN.md section 5).
+    if os.environ.get("DFX_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the library itself
+            pass
     L = C.CDLL(os.environ.get("DFX_LIBRARY", _LIB))  # DFX_LIBRARY: A/B a differently built libdfx.so
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     L.dfx_device_count.restype = i
