@@ -591,7 +591,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             jc.planes = c->d_img[par(k)];
             jc.plane_stride = (long long)plane;
             jc.pitch = c->W, jc.w = c->W, jc.h = c->H, jc.bw = (c->W + 7) / 8, jc.bh = (c->H + 7) / 8;
-            jc.n_pairs = p.nb, jc.y_first = c->img_slots;
+            jc.n_planes = 2 * p.nb, jc.n_x = p.nb, jc.y_first = c->img_slots;
             jc.tab = c->jpeg.d_tab, jc.dc = c->jpeg.d_dc, jc.bits = c->jpeg.d_bits;
             jc.plane_bits = c->jpeg.d_plane_bits, jc.plane_base = c->jpeg.d_plane_base;
             jc.stream = c->jpeg.d_stream[par(k)], jc.capacity_bytes = c->jpeg.capacity;
@@ -1014,6 +1014,64 @@ int dfx_submit_batch_jpeg(dfx_handle h, const uint8_t *const *frames, size_t fra
         return dfx_fail(h, DFX_ERR_INVALID, "NULL ticket");
     return jpeg_entry(h, frames, frame_pitch, n_frames, step, lower_bound, upper_bound, quality, jpg_x, jpg_y,
                       jpg_capacity, size_x, size_y, ticket);
+}
+
+int dfx_encode_jpeg(dfx_handle h, const uint8_t *const *planes, size_t pitch, int n, int quality, uint8_t *const *jpg,
+                    size_t jpg_capacity, uint32_t *sizes) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    (void)dfx_finish_tails(h, 0, -1);
+    if (n < 0)
+        return dfx_fail(h, DFX_ERR_INVALID, "n must be >= 0");
+    if (n == 0)
+        return DFX_OK;
+    if (!planes || !jpg || !sizes)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL plane, JPEG buffer or size array");
+    if (pitch < (size_t)h->W)
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
+    if (quality < 1 || quality > 100)
+        return dfx_fail(h, DFX_ERR_INVALID, "JPEG quality must be 1..100");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int B = h->engine->batch();
+    int rc = ensure_img_staging(h, B);
+    if (rc == DFX_OK)
+        rc = ensure_jpeg(h, B, quality);
+    if (rc != DFX_OK)
+        return rc;
+    const size_t plane = (size_t)h->W * h->H;
+    const int chunk_max = 2 * h->img_slots; // a staging set holds that many planes back to back
+    for (int i0 = 0; i0 < n; i0 += chunk_max) {
+        const int nc = std::min(chunk_max, n - i0);
+        for (int j = 0; j < nc; ++j)
+            HIPCHK(h, hipMemcpy2DAsync(h->d_img[0] + (size_t)j * plane, (size_t)h->W, planes[i0 + j], pitch, (size_t)h->W,
+                                       (size_t)h->H, hipMemcpyHostToDevice, h->stream));
+        JpegCtx jc;
+        jc.planes = h->d_img[0];
+        jc.plane_stride = (long long)plane;
+        jc.pitch = h->W, jc.w = h->W, jc.h = h->H, jc.bw = (h->W + 7) / 8, jc.bh = (h->H + 7) / 8;
+        jc.n_planes = nc, jc.n_x = nc, jc.y_first = 0;
+        jc.tab = h->jpeg.d_tab, jc.dc = h->jpeg.d_dc, jc.bits = h->jpeg.d_bits;
+        jc.plane_bits = h->jpeg.d_plane_bits, jc.plane_base = h->jpeg.d_plane_base;
+        jc.stream = h->jpeg.d_stream[0], jc.capacity_bytes = h->jpeg.capacity;
+        jc.info = h->jpeg.d_info[0], jc.hdr = h->jpeg.d_hdr;
+        jpeg_launch_encode(h->stream, jc);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const unsigned long long *hi = h->jpeg.h_info[0];
+        if (hi[1])
+            return dfx_fail(h, DFX_ERR_UNSUPPORTED,
+                            "JPEG: the planes do not compress below 4 bits per pixel (encode them on the host)");
+        HIPCHK(h, hipMemcpyAsync(h->jpeg.h_stream[0], h->jpeg.d_stream[0], (size_t)hi[0], hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (int j = 0; j < nc; ++j) {
+            const size_t sz = jpeg_assemble(h->jpeg.header, h->jpeg.h_stream[0] + hi[2 + 2 * j + 1], hi[2 + 2 * j], jpg[i0 + j],
+                                            jpg_capacity);
+            if (sz == 0)
+                return dfx_fail(h, DFX_ERR_INVALID, "JPEG: jpg_capacity is too small for an encoded plane");
+            sizes[i0 + j] = (uint32_t)sz;
+        }
+    }
+    return DFX_OK;
 }
 
 size_t dfx_jpeg_capacity(dfx_handle h) {

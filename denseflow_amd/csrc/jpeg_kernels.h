@@ -28,15 +28,15 @@ struct JpegInfo {
 };
 
 struct JpegCtx {
-    const unsigned char *planes; // plane p: planes + (p < n_pairs ? p : y_first + p - n_pairs) * plane_stride
+    const unsigned char *planes; // plane p: planes + (p < n_x ? p : y_first + p - n_x) * plane_stride
     long long plane_stride;
     int pitch, w, h, bw, bh;
-    int n_pairs, y_first;         // x planes 0..n_pairs-1, y planes start at index y_first
+    int n_planes, n_x, y_first;   // planes 0..n_x-1 are consecutive, the other n_planes - n_x start at index y_first
     const JpegTables *tab;
-    short *dc;                    // [2 * n_pairs][bw * bh] quantised DC of every block
-    unsigned *bits;               // [2 * n_pairs][bw * bh] AC bits of every block, then its exclusive bit offset
-    unsigned long long *plane_bits; // [2 * n_pairs] bits of each plane's entropy-coded segment (before stuffing)
-    unsigned long long *plane_base; // [2 * n_pairs] first byte of each plane's stream in `stream`
+    short *dc;                    // [n_planes][bw * bh] quantised DC of every block
+    unsigned *bits;               // [n_planes][bw * bh] AC bits of every block, then its exclusive bit offset
+    unsigned long long *plane_bits; // [n_planes] bits of each plane's entropy-coded segment (before stuffing)
+    unsigned long long *plane_base; // [n_planes] first byte of each plane's stream in `stream`
     unsigned *stream;             // shared output buffer, zeroed before the emit pass
     unsigned long long capacity_bytes;
     unsigned long long *info;     // JpegInfo + per-plane entries (device view of the page-locked block); written once

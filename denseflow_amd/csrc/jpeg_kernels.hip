@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64) void k_jpeg_blocks(JpegCtx c) {
     const JpegTables &T = *c.tab;
     const int by = blk / c.bw, bx = blk - by * c.bw;
     const unsigned char *P =
-        c.planes + (long long)(plane < c.n_pairs ? plane : c.y_first + plane - c.n_pairs) * c.plane_stride;
+        c.planes + (long long)(plane < c.n_x ? plane : c.y_first + plane - c.n_x) * c.plane_stride;
     // ---- load (ragged right / bottom edge: replicate the last column / row, like load_block of the host encoder)
     float a[8][8];
     const int x0 = bx * 8, y0 = by * 8;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(1024) void k_jpeg_scan(JpegCtx c) {
 __global__ void k_jpeg_layout(JpegCtx c) {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
-    const int n = 2 * c.n_pairs;
+    const int n = c.n_planes;
     unsigned long long at = 0;
     for (int p = 0; p < n; ++p) {
         const unsigned long long bits = c.plane_bits[p];
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_jpeg_zero(JpegCtx c) {
 } // namespace
 
 void jpeg_launch_encode(hipStream_t s, const JpegCtx &c) {
-    const int nblk = c.bw * c.bh, n_planes = 2 * c.n_pairs;
+    const int nblk = c.bw * c.bh, n_planes = c.n_planes;
     const dim3 grid((nblk + 63) / 64, n_planes);
     hipLaunchKernelGGL(k_jpeg_blocks<false>, grid, dim3(64), 0, s, c);
     hipLaunchKernelGGL(k_jpeg_scan, dim3(n_planes), dim3(1024), 0, s, c);

@@ -177,6 +177,8 @@ def load_library():
     L.dfx_submit_batch_jpeg.argtypes = [vp, C.POINTER(vp), sz, i, i, C.c_double, C.c_double, i, C.POINTER(vp),
                                         C.POINTER(vp), sz, u32p, u32p, C.POINTER(C.c_uint64)]
     L.dfx_submit_batch_jpeg.restype = i
+    L.dfx_encode_jpeg.argtypes = [vp, C.POINTER(vp), sz, i, i, C.POINTER(vp), sz, u32p]
+    L.dfx_encode_jpeg.restype = i
     L.dfx_jpeg_capacity.argtypes = [vp]
     L.dfx_jpeg_capacity.restype = sz
     L.dfx_wait.argtypes = [vp, C.c_uint64]
@@ -420,6 +422,21 @@ class FlowEngine:
                                                 float(bound), int(quality), (C.c_void_p * m)(*[b.ctypes.data for b in bx]),
                                                 (C.c_void_p * m)(*[b.ctypes.data for b in by]), cap, sx, sy))
         return ([bx[i][:sx[i]].tobytes() for i in range(m)], [by[i][:sy[i]].tobytes() for i in range(m)])
+
+    def encode_jpeg(self, planes, quality: int = 95):
+        """imencode(".jpg") of (H, W) uint8 planes on the device: a list of `bytes`."""
+        ps = [np.ascontiguousarray(p, dtype=np.uint8) for p in planes]
+        n = len(ps)
+        if n == 0:
+            return []
+        if any(p.shape != (self.height, self.width) for p in ps):
+            raise ValueError("plane shape does not match the engine")
+        cap = int(self._L.dfx_jpeg_capacity(self._h))
+        bufs = [np.empty(cap, np.uint8) for _ in range(n)]
+        sizes = (C.c_uint32 * n)()
+        self._check(self._L.dfx_encode_jpeg(self._h, (C.c_void_p * n)(*[p.ctypes.data for p in ps]), self.width, n,
+                                            int(quality), (C.c_void_p * n)(*[b.ctypes.data for b in bufs]), cap, sizes))
+        return [bufs[i][:sizes[i]].tobytes() for i in range(n)]
 
     def calc_optflows_u8_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,
                                 lower: float, upper: float, d_img_x_ptr: int, d_img_y_ptr: int, img_pitch: int,

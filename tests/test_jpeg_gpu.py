@@ -98,3 +98,20 @@ def test_submit_form_and_capacity_error(dfx, harness):
         rc = L.dfx_calc_batch_jpeg(eng._h, fp, w, n, 1, -20.0, 20.0, 95, (C.c_void_p * m)(*[b.ctypes.data for b in bx]),
                                    (C.c_void_p * m)(*[b.ctypes.data for b in by]), small, sx, sy)
         assert rc == 1 and b"jpg_capacity" in L.dfx_last_error(eng._h)
+
+
+def test_golden_files(dfx):
+    """tests/golden/jpeg_golden.npz (minted from the host encoder, tests/golden/make_jpeg_golden.py): the device encoder
+    on its own (dfx_encode_jpeg) must write those very bytes — smooth, ragged-edge + saturated, busy planes; q 95 / 50."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_golden.npz"))
+    for name in ("smooth_96x64", "ragged_45x27", "busy_64x64"):
+        plane = g[name + "_plane"]
+        h, w = plane.shape
+        with dfx.FlowEngine(w, h, "farn") as eng:
+            for q in (95, 50):
+                got = eng.encode_jpeg([plane, plane[::-1].copy(), plane], q)
+                want = g[f"{name}_q{q}_file"].tobytes()
+                assert got[0] == want and got[2] == want, (name, q)
+                assert got[1] != want

@@ -80,3 +80,21 @@ def test_simd_and_portable_transforms_are_now_bit_identical(harness):
             files.append(buf[:n].tobytes())
         harness.hh_jpeg_force_portable(0)
         assert files[0] == files[1], (w, h)
+
+
+def test_host_encoder_reproduces_the_golden_files(harness):
+    """The shell's encoder against tests/golden/jpeg_golden.npz (the GPU suite holds the device encoder to the same
+    bytes): a change of the shared tables or of the DCT arithmetic of either encoder cannot go unnoticed."""
+    import os
+
+    harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_golden.npz"))
+    for name in ("smooth_96x64", "ragged_45x27", "busy_64x64"):
+        plane = np.ascontiguousarray(g[name + "_plane"])
+        for q in (95, 50):
+            for portable in (0, 1):
+                harness.hh_jpeg_force_portable(portable)
+                buf = np.zeros(1 << 20, np.uint8)
+                n = harness.hh_encode_jpeg(plane.ctypes.data, plane.shape[1], plane.shape[0], q, buf.ctypes.data, buf.size)
+                assert buf[:n].tobytes() == g[f"{name}_q{q}_file"].tobytes(), (name, q, portable)
+    harness.hh_jpeg_force_portable(0)
