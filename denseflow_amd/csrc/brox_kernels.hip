@@ -14,6 +14,9 @@
 #include "tvl1_math_pk.h" // f2, pk_fma, the exact Newton division (shared with the TVL1 kernels)
 
 #define BROX_EPS2 1e-6f
+#ifndef BROX_SOR_DEBUG
+#define BROX_SOR_DEBUG 0
+#endif
 
 static inline dim3 bgrid(int w, int h, int z) { return dim3((w + 63) / 64, (h + 3) / 4, z); }
 
@@ -439,8 +442,16 @@ typedef float f2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 template <int S>
 __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set, int d_src, int n_sweeps, int tiles_x) {
     constexpr int TW = 64, TH = 64, HALO = 2 * S;
-    __shared__ float WU[TH][TW];
-    __shared__ float WV[TH][TW];
+    // w = u + du and v + dv of the tile, split by column parity: W*[x & 1][y][x >> 1].  A lane owns columns 2 * pcol and
+    // 2 * pcol + 1, so in a row-major [y][x] tile every access of a wave has a lane stride of TWO floats — a two-way
+    // bank conflict on all 16 reads and 4 writes of a half sweep (ds_read_b32 banks are (a / 4) mod 32,
+    // MI355X_MICROARCH.md), and those LDS cycles, not the arithmetic, were the sweeps' time.  Split by parity every
+    // access is lane-consecutive: pixel (y, 2p + k) is W*[k][y][p], its horizontal neighbours W*[1 - k][y][p] and
+    // W*[1 - k][y][p -/+ 1].
+    __shared__ float WU[2][TH][TW / 2];
+    __shared__ float WV[2][TH][TW / 2];
+#define WU_AT(ly, lx) WU[(lx)&1][ly][(lx) >> 1]
+#define WV_AT(ly, lx) WV[(lx)&1][ly][(lx) >> 1]
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
     const int tile = dfx_block_linear(); // neighbouring tiles re-read each other's 2*S-pixel halo: keep them in one L2
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -463,7 +474,11 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
     long long o[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
+#if BROX_SOR_DEBUG == 2 // measurement build only: the sweeps without the HBM traffic of the load phase (WRONG flows)
+        o[i] = 2 * (threadIdx.x & 31);
+#else
         o[i] = (inx0 && iny[i]) ? ((long long)(y + i) * pitch + x) : 0; // masked rows read element 0
+#endif
     auto ld2 = [](const float *P, long long off) -> f2 { return *reinterpret_cast<const f2_a8 *>(P + off); };
     auto mask = [&](f2 r, int i) -> f2 { return pk_set(inx0 && iny[i] ? r.x : 0.0f, inx1 && iny[i] ? r.y : 0.0f); };
     f2 r_gl[2], r_gd[2], r_idu[2], r_idv[2], r_nd[2], r_nu[2], r_nv[2], r_u[2], r_v[2], r_du[2], r_dv[2];
@@ -512,8 +527,8 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
         r_idu[i] = mask(pk_div_with_rcp((f2)(1.0f), den_u, pk_refined_rcp(den_u)), i);
         r_idv[i] = mask(pk_div_with_rcp((f2)(1.0f), den_v, pk_refined_rcp(den_v)), i);
         const f2 wu = r_u[i] + r_du[i], wv = r_v[i] + r_dv[i];
-        *reinterpret_cast<f2_a8 *>(&WU[ly0 + i][lx0]) = wu;
-        *reinterpret_cast<f2_a8 *>(&WV[ly0 + i][lx0]) = wv;
+        WU[0][ly0 + i][pcol] = wu.x, WU[1][ly0 + i][pcol] = wu.y;
+        WV[0][ly0 + i][pcol] = wv.x, WV[1][ly0 + i][pcol] = wv.y;
     }
     // colour pairs: pair q = {element 0: (row 0, column q), element 1: (row 1, column 1 - q)}; (x + y) parity of a patch
     // element (i, k) is (i + k) & 1 because x0, y0, lx0, ly0 are even, so pair q is what half sweep `q` updates
@@ -531,6 +546,9 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
     const float omega = c.omega, om1 = 1.0f - omega;
     constexpr int ROWS_PER_WAVE = 4;                         // 32 patch columns x 2 patch rows per wavefront
     const int band0 = (ly0 / ROWS_PER_WAVE) * ROWS_PER_WAVE; // first tile row of this wavefront
+#if BROX_SOR_DEBUG == 1 // measurement build only (scripts/build_variant.sh): load and store phases without the sweeps (WRONG flows)
+    n_sweeps = 0;
+#endif
     for (int sw = 0; sw < n_sweeps; ++sw) {
         // a wavefront whose rows can no longer influence the owned region skips its updates: after sweep s of n the
         // result is needed on the owned rows +- (2 (n - 1 - s) + 1)
@@ -543,10 +561,10 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
                 const int ax = lx0 + q, bx = lx0 + 1 - q;
                 const int axl = q ? lx0 : xm, axr = q ? xp : lx0 + 1; // left / right neighbour columns of element 0
                 const int bxl = q ? xm : lx0, bxr = q ? lx0 + 1 : xp; // ... of element 1
-                const f2 Lu = pk_set(WU[ly0][axl], WU[ly0 + 1][bxl]), Ru = pk_set(WU[ly0][axr], WU[ly0 + 1][bxr]);
-                const f2 Du = pk_set(WU[ym][ax], WU[ly0][bx]), Uu = pk_set(WU[ly0 + 1][ax], WU[yp][bx]);
-                const f2 Lv = pk_set(WV[ly0][axl], WV[ly0 + 1][bxl]), Rv = pk_set(WV[ly0][axr], WV[ly0 + 1][bxr]);
-                const f2 Dv = pk_set(WV[ym][ax], WV[ly0][bx]), Uv = pk_set(WV[ly0 + 1][ax], WV[yp][bx]);
+                const f2 Lu = pk_set(WU_AT(ly0, axl), WU_AT(ly0 + 1, bxl)), Ru = pk_set(WU_AT(ly0, axr), WU_AT(ly0 + 1, bxr));
+                const f2 Du = pk_set(WU_AT(ym, ax), WU_AT(ly0, bx)), Uu = pk_set(WU_AT(ly0 + 1, ax), WU_AT(yp, bx));
+                const f2 Lv = pk_set(WV_AT(ly0, axl), WV_AT(ly0 + 1, bxl)), Rv = pk_set(WV_AT(ly0, axr), WV_AT(ly0 + 1, bxr));
+                const f2 Dv = pk_set(WV_AT(ym, ax), WV_AT(ly0, bx)), Uv = pk_set(WV_AT(ly0 + 1, ax), WV_AT(yp, bx));
                 const f2 su = (((gl[q] * Lu + gr[q] * Ru) + gd[q] * Du) + gu[q] * Uu) - gs[q] * uu[q];
                 const f2 sv = (((gl[q] * Lv + gr[q] * Rv) + gd[q] * Dv) + gu[q] * Uv) - gs[q] * vv[q];
                 const f2 du_n = om1 * du[q] + omega * (idu[q] * ((su - nu[q]) - nd[q] * dv[q]));
@@ -556,10 +574,10 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
                 // publish right away: this half sweep reads w only at pixels of the other colour (or, clamped, at the
                 // pixel's own entry) and each entry of this colour is written by the one thread that owns it
                 const f2 wu = uu[q] + du_n, wv = vv[q] + dv_n;
-                WU[ly0][ax] = wu.x;
-                WU[ly0 + 1][bx] = wu.y;
-                WV[ly0][ax] = wv.x;
-                WV[ly0 + 1][bx] = wv.y;
+                WU_AT(ly0, ax) = wu.x;
+                WU_AT(ly0 + 1, bx) = wu.y;
+                WV_AT(ly0, ax) = wv.x;
+                WV_AT(ly0 + 1, bx) = wv.y;
             }
             __syncthreads();
         }
@@ -584,6 +602,8 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
         }
     }
 }
+#undef WU_AT
+#undef WV_AT
 
 __global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int uv_set, int d_set) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
