@@ -40,7 +40,6 @@ class BroxEngine final : public AlgoEngine {
     float *d_frames = nullptr;
     int *d_frame_slots = nullptr, *h_slots_pinned = nullptr;
     int B = 0;
-    int sor_r2 = 0; // 1: the round-2 fused SOR kernel (dfx_params.variant & DFX_VAR_BROX_SOR_R2)
     float *d_planes = nullptr;
     long long plane_stride = 0, slot_stride = 0;
     PairDesc *d_pairs = nullptr, *h_pairs_pinned = nullptr;
@@ -66,7 +65,6 @@ int BroxEngine::create() {
     const dfx_params &p = c->prm;
     if (p.impl < 0 || p.impl > 1)
         return dfx_fail(c, DFX_ERR_INVALID, "brox: impl must be 0 (tuned) or 1 (simple)");
-    sor_r2 = (p.variant & DFX_VAR_BROX_SOR_R2) ? 1 : 0;
     if (!(p.brox_scale_factor > 0.f && p.brox_scale_factor < 1.f) || !(p.brox_alpha > 0.f) ||
         p.brox_inner_iterations < 0 || p.brox_outer_iterations < 1 || p.brox_solver_iterations < 0)
         return dfx_fail(c, DFX_ERR_INVALID, "invalid Brox parameters");
@@ -191,7 +189,7 @@ int BroxEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
             } else {
                 const int S = brox_fused_sweeps();
                 for (int si = 0; si < p.brox_solver_iterations; si += S) {
-                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si), sor_r2);
+                    brox_launch_sor_fused(c->stream, x, uv, ds, std::min(S, p.brox_solver_iterations - si));
                     ds ^= 1; // it wrote the other set
                 }
             }

@@ -44,8 +44,8 @@ void brox_launch_stage1(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_
 void brox_launch_stage2(hipStream_t s, const BroxLevelCtx &c);
 void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set, int color); // in place
 // n_sweeps (<= brox_fused_sweeps()) full red+black sweeps in one launch (64 x 64 LDS tile, recomputed halo); writes
-// set d_src ^ 1.  r2 != 0: the round-2 kernel (cross-check / A-B), otherwise the packed round-3 kernel.
-void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int r2);
+// set d_src ^ 1
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps);
 int brox_fused_sweeps();
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set);
 // (u,v)[uv_set ^ 1] at the finer geometry = bicubic(u,v[uv_set]) * mul

@@ -272,161 +272,16 @@ __global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, in
     DV[o] = dv_n;
 }
 
-// Fused SOR: several full red+black sweeps per launch on an LDS tile; each thread owns a 2-column x 2-row patch
-// (14 values x 4 pixels stay under 128 VGPRs).  The 9 per-pixel coefficients and u, v stay in registers, only
-// w = u + du (the quantity neighbours read) lives in LDS.  Tile origins are even, so a pixel's colour is a
-// compile-time function of its position in the patch.  Every half-sweep shrinks the valid region by one
-// pixel; a halo of 2 pixels per sweep is recomputed redundantly and only the inner region is written
-// back.  Same per-pixel expression, same order: bit-identical to the one-launch-per-half-sweep form.
-#define BROX_PR 2 // patch rows per thread
-// Tile BROX_TW x BROX_TH (one thread per 2x2 patch), up to BROX_S sweeps per launch (halo 2*BROX_S).
-// MODE 0: two barriers per half sweep (update | barrier | publish w | barrier) — the first form, kept for A/B.
-// MODE 1: one.  A half sweep of colour c reads w only at pixels of colour 1-c (the four neighbours; at a clamped tile
-//         edge the pixel's own entry) and writes w only at pixels of colour c, each by the one thread that owns it, so
-//         publishing right after the update races with nothing; only the next half sweep has to wait.
-// MODE 2: as 1, and a wavefront (= a band of 4 tile rows) whose rows can no longer influence the owned region skips
-//         its update: after sweep s of n the result is needed on the owned rows +- (2(n-1-s)+1), the halo is 2*BROX_S.
-template <int BROX_TW, int BROX_TH, int BROX_S, int MODE = 0>
-__global__ __launch_bounds__(BROX_TW *BROX_TH / 4) void k_brox_sor_fused(BroxLevelCtx c, int uv_set, int d_src,
-                                                                         int n_sweeps, int tiles_x) {
-    constexpr int BROX_HALO = 2 * BROX_S;
-    __shared__ float WU[BROX_TH][BROX_TW];
-    __shared__ float WV[BROX_TH][BROX_TW];
-    const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
-    const int tile = dfx_block_linear(); // neighbouring tiles re-read each other's 2*S-pixel halo: keep them in one L2
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int x0 = tx * (BROX_TW - 2 * BROX_HALO) - BROX_HALO; // even
-    const int y0 = ty * (BROX_TH - 2 * BROX_HALO) - BROX_HALO; // even
-    const int pcol = threadIdx.x % (BROX_TW / 2), prow = threadIdx.x / (BROX_TW / 2);
-    const int lx0 = 2 * pcol, ly0 = BROX_PR * prow;
-
-    const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
-    const float *DU = bplane(c, b, du_plane(d_src)), *DV = bplane(c, b, dv_plane(d_src));
-    float *DUo = bplane(c, b, du_plane(d_src ^ 1)), *DVo = bplane(c, b, dv_plane(d_src ^ 1));
-    const float *GX = bplane(c, b, BROX_PL_GX), *GY = bplane(c, b, BROX_PL_GY);
-    const float *IDU = bplane(c, b, BROX_PL_IDU), *IDV = bplane(c, b, BROX_PL_IDV);
-    const float *NDUDV = bplane(c, b, BROX_PL_NDUDV), *NU = bplane(c, b, BROX_PL_NU), *NV = bplane(c, b, BROX_PL_NV);
-
-    float gl[BROX_PR][2], gr[BROX_PR][2], gd[BROX_PR][2], gu[BROX_PR][2], gs[BROX_PR][2], idu[BROX_PR][2], idv[BROX_PR][2], nd[BROX_PR][2], nu[BROX_PR][2], nv[BROX_PR][2];
-    float uu[BROX_PR][2], vv[BROX_PR][2], du[BROX_PR][2], dv[BROX_PR][2];
-#pragma unroll
-    for (int i = 0; i < BROX_PR; ++i) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int x = x0 + lx0 + k, y = y0 + ly0 + i;
-            const bool in = x >= 0 && x < w && y >= 0 && y < h;
-            const long long o = in ? ((long long)y * pitch + x) : 0;
-            gl[i][k] = in ? GX[o] : 0.0f;
-            gr[i][k] = (in && x + 1 < w) ? GX[o + 1] : 0.0f;
-            gd[i][k] = in ? GY[o] : 0.0f;
-            gu[i][k] = (in && y + 1 < h) ? GY[o + pitch] : 0.0f;
-            gs[i][k] = ((gl[i][k] + gr[i][k]) + gd[i][k]) + gu[i][k];
-            // stage 2 of the definition, 1 / (data term + sum of diffusivities), evaluated here from the raw planes:
-            // the fused path never launches k_brox_stage2 (same expression, same bits)
-            idu[i][k] = in ? 1.0f / (IDU[o] + gs[i][k]) : 0.0f;
-            idv[i][k] = in ? 1.0f / (IDV[o] + gs[i][k]) : 0.0f;
-            nd[i][k] = in ? NDUDV[o] : 0.0f;
-            nu[i][k] = in ? NU[o] : 0.0f;
-            nv[i][k] = in ? NV[o] : 0.0f;
-            uu[i][k] = in ? u[o] : 0.0f;
-            vv[i][k] = in ? v[o] : 0.0f;
-            du[i][k] = in ? DU[o] : 0.0f;
-            dv[i][k] = in ? DV[o] : 0.0f;
-            WU[ly0 + i][lx0 + k] = uu[i][k] + du[i][k];
-            WV[ly0 + i][lx0 + k] = vv[i][k] + dv[i][k];
-        }
-    }
-    __syncthreads();
-    const float omega = c.omega;
-    if (MODE >= 1) {
-        constexpr int ROWS_PER_WAVE = BROX_PR * (64 / (BROX_TW / 2)); // BROX_TW / 2 patch columns per patch row
-        const int band0 = (ly0 / ROWS_PER_WAVE) * ROWS_PER_WAVE;     // first tile row of this wavefront
-        for (int sw = 0; sw < n_sweeps; ++sw) {
-            const int m = 2 * (n_sweeps - 1 - sw) + 1;
-            const bool live = MODE < 2 || (band0 + ROWS_PER_WAVE - 1 >= BROX_HALO - m && band0 < BROX_TH - BROX_HALO + m);
-#pragma unroll
-            for (int color = 0; color < 2; ++color) {
-                if (live) {
-#pragma unroll
-                    for (int i = 0; i < BROX_PR; ++i) {
-                        const int k = (i + color) & 1;
-                        const int lx = lx0 + k, ly = ly0 + i;
-                        const int lxl = max(lx - 1, 0), lxr = min(lx + 1, BROX_TW - 1);
-                        const int lyd = max(ly - 1, 0), lyu = min(ly + 1, BROX_TH - 1);
-                        const float su = (((gl[i][k] * WU[ly][lxl] + gr[i][k] * WU[ly][lxr]) + gd[i][k] * WU[lyd][lx]) +
-                                          gu[i][k] * WU[lyu][lx]) -
-                                         gs[i][k] * uu[i][k];
-                        const float sv = (((gl[i][k] * WV[ly][lxl] + gr[i][k] * WV[ly][lxr]) + gd[i][k] * WV[lyd][lx]) +
-                                          gu[i][k] * WV[lyu][lx]) -
-                                         gs[i][k] * vv[i][k];
-                        const float du_n =
-                            (1.0f - omega) * du[i][k] + omega * (idu[i][k] * ((su - nu[i][k]) - nd[i][k] * dv[i][k]));
-                        const float dv_n =
-                            (1.0f - omega) * dv[i][k] + omega * (idv[i][k] * ((sv - nv[i][k]) - nd[i][k] * du_n));
-                        du[i][k] = du_n;
-                        dv[i][k] = dv_n;
-                        WU[ly][lx] = uu[i][k] + du_n;
-                        WV[ly][lx] = vv[i][k] + dv_n;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    } else
-    for (int sw = 0; sw < n_sweeps; ++sw) {
-#pragma unroll
-        for (int color = 0; color < 2; ++color) {
-#pragma unroll
-            for (int i = 0; i < BROX_PR; ++i) {
-                // (x + y) parity of patch element (i, k) is (i + k) & 1 because x0, y0, lx0, ly0 are even
-                const int k = (i + color) & 1;
-                const int lx = lx0 + k, ly = ly0 + i;
-                const int lxl = max(lx - 1, 0), lxr = min(lx + 1, BROX_TW - 1);
-                const int lyd = max(ly - 1, 0), lyu = min(ly + 1, BROX_TH - 1);
-                const float su = (((gl[i][k] * WU[ly][lxl] + gr[i][k] * WU[ly][lxr]) + gd[i][k] * WU[lyd][lx]) +
-                                  gu[i][k] * WU[lyu][lx]) -
-                                 gs[i][k] * uu[i][k];
-                const float sv = (((gl[i][k] * WV[ly][lxl] + gr[i][k] * WV[ly][lxr]) + gd[i][k] * WV[lyd][lx]) +
-                                  gu[i][k] * WV[lyu][lx]) -
-                                 gs[i][k] * vv[i][k];
-                const float du_n =
-                    (1.0f - omega) * du[i][k] + omega * (idu[i][k] * ((su - nu[i][k]) - nd[i][k] * dv[i][k]));
-                const float dv_n =
-                    (1.0f - omega) * dv[i][k] + omega * (idv[i][k] * ((sv - nv[i][k]) - nd[i][k] * du_n));
-                du[i][k] = du_n;
-                dv[i][k] = dv_n;
-            }
-            __syncthreads(); // every read of the old w of this colour's neighbours is done
-#pragma unroll
-            for (int i = 0; i < BROX_PR; ++i) {
-                const int k = (i + color) & 1;
-                WU[ly0 + i][lx0 + k] = uu[i][k] + du[i][k];
-                WV[ly0 + i][lx0 + k] = vv[i][k] + dv[i][k];
-            }
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < BROX_PR; ++i) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int lx = lx0 + k, ly = ly0 + i;
-            const int x = x0 + lx, y = y0 + ly;
-            if (lx >= BROX_HALO && lx < BROX_TW - BROX_HALO && ly >= BROX_HALO && ly < BROX_TH - BROX_HALO && x < w &&
-                y < h) {
-                const long long o = (long long)y * pitch + x;
-                DUo[o] = du[i][k];
-                DVo[o] = dv[i][k];
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// The fused SOR, round 3 (the tuned default).  Same tile (64 x 64, one thread per 2x2 patch, 2*S-pixel recomputed halo,
-// S sweeps per launch), same per-pixel expression in the same order — bit-identical to k_brox_sor and to the round-2
-// kernel above — but built for the two things the round-2 counters showed (VALU busy 33 %, 63 % of wave cycles waiting,
-// one 1024-thread workgroup per CU: profiles/round2/brox/):
+// The fused SOR (the tuned default): S full red+black sweeps per launch on a 64 x 64 LDS tile, one thread per 2-column x
+// 2-row patch, the 9 per-pixel coefficients and u, v in registers, only w = u + du (what neighbours read) in LDS.  Tile
+// origins are even, so a pixel's colour is a compile-time function of its position in the patch.  Every half sweep
+// shrinks the valid region by one pixel: a halo of 2*S pixels is recomputed redundantly and only the inner region is
+// written back (to the OTHER du / dv set: with an in-place update neighbouring workgroups of one launch race on each
+// other's halo).  Same per-pixel expression, same order: bit-identical to k_brox_sor, the one-launch-per-half-sweep form.
+// One barrier per half sweep: a half sweep of colour c reads w only at pixels of colour 1-c (the four neighbours; at a
+// clamped tile edge the pixel's own entry) and writes w only at pixels of colour c, each by the thread that owns it.
+// Round 3 rebuilt the round-2 kernel (VALU busy 33 %, 63 % of wave cycles waiting: profiles/round2/brox/) around:
 //   * LOAD PHASE.  The round-2 kernel fetched each of its 15 per-pixel inputs with a dword load whose lanes are 8 bytes
 //     apart (x = 2 * lane + k): 60 load instructions per thread, each using half of the bytes the texture-address unit
 //     walks.  Here a patch row is one 8-byte load per plane (x0, lx0 are even and the pitch is a multiple of 64, so the
@@ -693,15 +548,11 @@ void brox_launch_sor(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set
 // pairs/s at 1080p against 153 / 141 for 3 / 2 sweeps and 145 for 64x32 and 128x32 tiles).
 constexpr int BROX_SWEEPS = 5;
 int brox_fused_sweeps() { return BROX_SWEEPS; }
-// r2 = the round-2 kernel (dfx_params.variant & DFX_VAR_BROX_SOR_R2), otherwise k_brox_sor_pk
-void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps, int r2) {
+void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_src, int n_sweeps) {
     constexpr int TW = 64, TH = 64, S = BROX_SWEEPS;
     const int tiles_x = (c.w + (TW - 4 * S) - 1) / (TW - 4 * S), tiles_y = (c.h + (TH - 4 * S) - 1) / (TH - 4 * S);
     const dim3 grid(tiles_x * tiles_y, 1, c.n_pairs), block(TW * TH / 4);
-    if (r2)
-        hipLaunchKernelGGL((k_brox_sor_fused<TW, TH, S, 2>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
-    else
-        hipLaunchKernelGGL((k_brox_sor_pk<S>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
+    hipLaunchKernelGGL((k_brox_sor_pk<S>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
 }
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set) {
     hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set);

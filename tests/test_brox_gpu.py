@@ -78,15 +78,11 @@ def test_large_pyramid_1080p(dfx, oracle):
     assert np.abs(out - gt)[64:-64, 64:-64].mean() < 0.05
 
 
-@pytest.mark.parametrize("variant", ["r3", "r2"])
-def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle, variant):
-    """The fused SOR kernels (LDS tile, recomputed halo, five sweeps per launch) must not change a bit relative to the
-    simple one-launch-per-half-sweep form, for even and odd solver-iteration counts: the round-3 default (8-byte loads,
-    the two pixels of a half sweep as packed float2 math, exact Newton reciprocals) and the round-2 kernel it replaced
-    (dfx_params.variant = DFX_VAR_BROX_SOR_R2)."""
-    from denseflow_amd import engine as E
-
-    knobs = {"variant": E.VAR_BROX_SOR_R2} if variant == "r2" else {}
+def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
+    """The fused SOR kernel (LDS tile split by column parity, recomputed halo, five sweeps per launch, 8-byte loads, the
+    two pixels of a half sweep as packed float2 math, exact Newton reciprocals) must not change a bit relative to the
+    simple one-launch-per-half-sweep form, for even and odd solver-iteration counts."""
+    knobs = {}
     # large enough that workgroups of one launch are NOT all co-resident: an in-place update of du/dv would
     # race with neighbours reading their halo (this caught exactly that bug; the kernels ping-pong two sets).
     # odd width and height: the right-most 8-byte pair and the last patch row straddle the image border
