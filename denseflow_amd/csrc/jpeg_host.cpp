@@ -34,11 +34,10 @@ void put16(std::vector<unsigned char> &o, int v) {
 
 void jpeg_build_tables(int quality, JpegTables &t, unsigned char q_out[64]) {
     dfx_jpeg_quantiser(quality, q_out);
-    for (int u = 0; u < 8; ++u)
-        for (int x = 0; x < 8; ++x)
-            t.c[u][x] = kDfxJpegDctBasis[u][x];
-    for (int i = 0; i < 64; ++i)
-        t.rq[i] = 1.0f / (float)q_out[i];
+    for (int i = 0; i < 64; ++i) {
+        t.div[i] = 8u * q_out[i];
+        t.magic[i] = dfx_jpeg_divide_magic(t.div[i]);
+    }
     build_huff(kDfxJpegDcBits, kDfxJpegDcVal, t.dc_code, t.dc_len, 12);
     build_huff(kDfxJpegAcBits, kDfxJpegAcVal, t.ac_code, t.ac_len, 256);
     for (int k = 0; k < 64; ++k)

@@ -10,8 +10,8 @@
 #include <vector>
 
 struct JpegTables { // one per (handle, quality), in device memory
-    float c[8][8];  // DCT basis (include/dfx_jpeg_tables.h)
-    float rq[64];   // 1 / quantiser, natural order
+    unsigned div[64];   // 8 q: the divisor of libjpeg's quantisation (include/dfx_jpeg_tables.h), natural order
+    unsigned magic[64]; // dfx_jpeg_divide_magic(div)
     unsigned short dc_code[12];
     unsigned char dc_len[12];
     unsigned short ac_code[256];

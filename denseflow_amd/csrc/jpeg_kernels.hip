@@ -4,9 +4,10 @@
 // 56-57), which its single save thread runs for every pair (src/denseflow_gpu.cpp:396-454).  With the flow bounding
 // already on the device (quantize_kernels.hip) the planes never have to leave it uncompressed: the entropy-coded
 // segments do — ~0.1 of a plane's bytes for flow images — and the host only adds the file header and the 0xFF byte
-// stuffing.  Output is byte-identical to the shell's host encoder (src/image_io.cpp: imencodeJpeg; shared tables in
-// include/dfx_jpeg_tables.h): same DCT arithmetic (one product, seven fused multiply-adds per output, columns then
-// rows), round-half-even quantisation, the same code construction.
+// stuffing.  Output is byte-identical to libjpeg(-turbo)'s — the library behind cv::imencode — and to the shell's host
+// encoder (src/image_io.cpp: imencodeJpeg): libjpeg's JDCT_ISLOW integer transform and quantisation rule, shared with
+// the host encoder through include/dfx_jpeg_tables.h, the Annex K tables, the same code construction
+// (tests/test_jpeg_libjpeg_pin.py, tests/test_jpeg_gpu.py).
 //
 // Structure (everything on the batch's compute stream):
 //   1. k_jpeg_blocks<false>  one thread per 8x8 block: DCT + quantisation in registers, the block's AC bit count and its
@@ -16,14 +17,16 @@
 //   3. k_jpeg_layout         one thread: byte offset of every plane's stream in the shared buffer, totals to the host
 //                            (mapped page-locked memory);
 //   4. zero-fill of the used part of the shared buffer, then
-//      k_jpeg_blocks<true>   the same DCT again (1024 FMAs per block are cheaper than keeping 128 bytes of coefficients
-//                            per block in HBM), codes appended at the block's bit offset with 32-bit atomic ORs
+//      k_jpeg_blocks<true>   the same DCT again (a few hundred integer operations per block are cheaper than keeping
+//                            128 bytes of coefficients per block in HBM), codes appended at the block's bit offset with
+//                            32-bit atomic ORs
 //                            (big-endian words: JPEG bit order is MSB first).
 // One thread per block is deliberate: a plane has 32 400 blocks (1080p) and a batch 258 planes — millions of
 // independent blocks, so there is no need to split a block over lanes, and the per-block code is the host encoder's
 // loop line for line.  Cost: ~1 ms per 129-pair batch at 1080p, against ~300 ms of TVL1.
 #include <hip/hip_runtime.h>
 
+#include "../../include/dfx_jpeg_tables.h"
 #include "jpeg_kernels.h"
 
 namespace {
@@ -70,40 +73,32 @@ __global__ __launch_bounds__(64) void k_jpeg_blocks(JpegCtx c) {
     const int by = blk / c.bw, bx = blk - by * c.bw;
     const unsigned char *P =
         c.planes + (long long)(plane < c.n_x ? plane : c.y_first + plane - c.n_x) * c.plane_stride;
-    // ---- load (ragged right / bottom edge: replicate the last column / row, like load_block of the host encoder)
-    float a[8][8];
+    // ---- load (ragged right / bottom edge: replicate the last column / row, like libjpeg's edge expansion and
+    //      fdct_quant_scalar of the host encoder)
+    int a[8][8];
     const int x0 = bx * 8, y0 = by * 8;
 #pragma unroll
     for (int y = 0; y < 8; ++y) {
         const unsigned char *row = P + (long long)min(y0 + y, c.h - 1) * c.pitch;
 #pragma unroll
         for (int x = 0; x < 8; ++x)
-            a[y][x] = (float)row[min(x0 + x, c.w - 1)] - 128.f;
+            a[y][x] = (int)row[min(x0 + x, c.w - 1)] - 128;
     }
-    // ---- forward DCT: columns (t[v][x] = sum_y c[v][y] a[y][x]), then rows (r = sum_x c[u][x] t[v][x]); one product
-    //      and seven FMAs in index order, as dct_rows / fdct_quant_portable of src/image_io.cpp
-    float t[8][8];
+    // ---- forward DCT: libjpeg's JDCT_ISLOW, rows then columns (include/dfx_jpeg_tables.h) — integer arithmetic, the
+    //      host encoder's and libjpeg's own coefficients
 #pragma unroll
-    for (int v = 0; v < 8; ++v)
+    for (int y = 0; y < 8; ++y)
+        dfx_jpeg_fdct_islow_1d<true>(a[y][0], a[y][1], a[y][2], a[y][3], a[y][4], a[y][5], a[y][6], a[y][7]);
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            float s = T.c[v][0] * a[0][x];
-#pragma unroll
-            for (int y = 1; y < 8; ++y)
-                s = __builtin_fmaf(T.c[v][y], a[y][x], s);
-            t[v][x] = s;
-        }
+    for (int x = 0; x < 8; ++x)
+        dfx_jpeg_fdct_islow_1d<false>(a[0][x], a[1][x], a[2][x], a[3][x], a[4][x], a[5][x], a[6][x], a[7][x]);
     int dc = 0;
     unsigned long long nz = 0; // bit k: zig-zag position k holds a non-zero coefficient
 #pragma unroll
     for (int v = 0; v < 8; ++v)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            float s = T.c[u][0] * t[v][0];
-#pragma unroll
-            for (int x = 1; x < 8; ++x)
-                s = __builtin_fmaf(T.c[u][x], t[v][x], s);
-            const int q = (int)__builtin_rintf(s * T.rq[v * 8 + u]); // round half to even = lrintf / cvtps2dq
+            const int q = dfx_jpeg_quantise(a[v][u], T.div[v * 8 + u], T.magic[v * 8 + u]); // divide by 8 q, half away from 0
             const int k = T.nat2zig[v * 8 + u];
             if (v == 0 && u == 0) {
                 dc = q;

@@ -1,28 +1,28 @@
 /*
  * include/dfx_jpeg_tables.h — the constants of the baseline JPEG encoder (ITU-T T.81, 8-bit gray), shared by the host
  * encoder of the shell (src/image_io.cpp: imencodeJpeg) and the device encoder of libdfx
- * (denseflow_amd/csrc/jpeg_kernels.hip: dfx_calc_batch_jpeg).  Both must produce the same bytes, so both read the SAME
- * tables — in particular the DCT basis is a table of float literals, not a run-time cos() whose last bit could depend
- * on the compiler or the libm.
+ * (denseflow_amd/csrc/jpeg_kernels.hip: dfx_calc_batch_jpeg).  Both must produce the same bytes, so both use the SAME
+ * tables and the SAME transform, which is integer arithmetic throughout.
  *
  * Replaces (together with the two encoders) the reference's `imencode(".jpg", ...)` of every bounded flow plane
- * (/root/reference/src/common.cpp:56-57): baseline sequential DCT, one component, the Annex K luminance quantiser
- * scaled for quality 95 (OpenCV's default) and the Annex K luminance Huffman tables.
+ * (/root/reference/src/common.cpp:56-57).  OpenCV's imencode drives libjpeg(-turbo) with its defaults: baseline
+ * sequential DCT, one component, the Annex K luminance quantiser scaled for quality 95, the Annex K luminance Huffman
+ * tables, and libjpeg's default forward transform JDCT_ISLOW with its quantisation rule.  libjpeg is a third-party
+ * dependency of the reference that is not in /root/reference; its published algorithm (IJG jfdctint.c: the
+ * Loeffler-Ligtenberg-Moschytz 8-point DCT in 13-bit fixed point, two passes; jcdctmgr.c: divide by 8 q, round half away
+ * from zero) is restated below.  PINNED: a libjpeg-turbo is importable in this container through Pillow, and with this
+ * transform both encoders write files that are byte-identical to libjpeg-turbo's for the same plane and quality
+ * (tests/test_jpeg_libjpeg_pin.py, live against Pillow where it is installed, and against tests/golden/
+ * jpeg_libjpeg_golden.npz everywhere).
  */
 #ifndef DFX_JPEG_TABLES_H
 #define DFX_JPEG_TABLES_H
 
-/* orthonormal DCT-II basis: c[u][x] = (float)(cos((2x + 1) u pi / 16) * (u == 0 ? sqrt(1/8) : 1/2)), from double */
-static const float kDfxJpegDctBasis[8][8] = {
-    {0x1.6a09e6p-2f, 0x1.6a09e6p-2f, 0x1.6a09e6p-2f, 0x1.6a09e6p-2f, 0x1.6a09e6p-2f, 0x1.6a09e6p-2f, 0x1.6a09e6p-2f, 0x1.6a09e6p-2f},
-    {0x1.f6297cp-2f, 0x1.a9b662p-2f, 0x1.1c73b4p-2f, 0x1.8f8b84p-4f, -0x1.8f8b84p-4f, -0x1.1c73b4p-2f, -0x1.a9b662p-2f, -0x1.f6297cp-2f},
-    {0x1.d906bcp-2f, 0x1.87de2ap-3f, -0x1.87de2ap-3f, -0x1.d906bcp-2f, -0x1.d906bcp-2f, -0x1.87de2ap-3f, 0x1.87de2ap-3f, 0x1.d906bcp-2f},
-    {0x1.a9b662p-2f, -0x1.8f8b84p-4f, -0x1.f6297cp-2f, -0x1.1c73b4p-2f, 0x1.1c73b4p-2f, 0x1.f6297cp-2f, 0x1.8f8b84p-4f, -0x1.a9b662p-2f},
-    {0x1.6a09e6p-2f, -0x1.6a09e6p-2f, -0x1.6a09e6p-2f, 0x1.6a09e6p-2f, 0x1.6a09e6p-2f, -0x1.6a09e6p-2f, -0x1.6a09e6p-2f, 0x1.6a09e6p-2f},
-    {0x1.1c73b4p-2f, -0x1.f6297cp-2f, 0x1.8f8b84p-4f, 0x1.a9b662p-2f, -0x1.a9b662p-2f, -0x1.8f8b84p-4f, 0x1.f6297cp-2f, -0x1.1c73b4p-2f},
-    {0x1.87de2ap-3f, -0x1.d906bcp-2f, 0x1.d906bcp-2f, -0x1.87de2ap-3f, -0x1.87de2ap-3f, 0x1.d906bcp-2f, -0x1.d906bcp-2f, 0x1.87de2ap-3f},
-    {0x1.8f8b84p-4f, -0x1.1c73b4p-2f, 0x1.a9b662p-2f, -0x1.f6297cp-2f, 0x1.f6297cp-2f, -0x1.a9b662p-2f, 0x1.1c73b4p-2f, -0x1.8f8b84p-4f},
-};
+#if defined(__HIPCC__)
+#define DFX_JPEG_HD __host__ __device__
+#else
+#define DFX_JPEG_HD
+#endif
 
 /* zig-zag scan (position -> natural index), Annex K.1 luminance quantiser, Annex K.3 luminance Huffman tables */
 static const unsigned char kDfxJpegZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
@@ -56,5 +56,58 @@ static inline void dfx_jpeg_quantiser(int quality, unsigned char q[64]) {
         q[i] = (unsigned char)(v < 1 ? 1 : (v > 255 ? 255 : v));
     }
 }
+
+#ifdef __cplusplus
+/* One pass of libjpeg's JDCT_ISLOW forward DCT (IJG jfdctint.c) over one line of eight values, for any integer type I
+ * with + - * << >> (int on the device and in the portable host form, a vector of eight ints in the host's SIMD form —
+ * integer arithmetic: every form gives the same coefficients).  FIRST = true: pass 1 (libjpeg: rows), results scaled
+ * up by 2^PASS1; FIRST = false: pass 2 (columns), the scaling removed again.  After both passes the block holds 8x the
+ * DCT coefficients; the factor is part of the divisor (dfx_jpeg_quantise).  CONST = 13 bits: products stay below 2^31
+ * for 8-bit samples (jfdctint.c's own range analysis). */
+template <bool FIRST, class I>
+DFX_JPEG_HD inline void dfx_jpeg_fdct_islow_1d(I &d0, I &d1, I &d2, I &d3, I &d4, I &d5, I &d6, I &d7) {
+    const int CONST = 13, PASS1 = 2;
+    const int S = FIRST ? CONST - PASS1 : CONST + PASS1; /* descale shift of the odd part and of outputs 2 and 6 */
+    const int R = 1 << (S - 1);
+    I t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6, t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
+    const I t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+    if (FIRST) {
+        d0 = (t10 + t11) << PASS1;
+        d4 = (t10 - t11) << PASS1;
+    } else {
+        d0 = (t10 + t11 + (1 << (PASS1 - 1))) >> PASS1;
+        d4 = (t10 - t11 + (1 << (PASS1 - 1))) >> PASS1;
+    }
+    I z1 = (t12 + t13) * 4433;               /* FIX(0.541196100) */
+    d2 = (z1 + t13 * 6270 + R) >> S;         /* FIX(0.765366865) */
+    d6 = (z1 - t12 * 15137 + R) >> S;        /* FIX(1.847759065) */
+    z1 = t4 + t7;
+    I z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+    const I z5 = (z3 + z4) * 9633;           /* FIX(1.175875602) */
+    t4 = t4 * 2446;                          /* FIX(0.298631336) */
+    t5 = t5 * 16819;                         /* FIX(2.053119869) */
+    t6 = t6 * 25172;                         /* FIX(3.072711026) */
+    t7 = t7 * 12299;                         /* FIX(1.501321110) */
+    z1 = z1 * -7373;                         /* FIX(0.899976223) */
+    z2 = z2 * -20995;                        /* FIX(2.562915447) */
+    z3 = z3 * -16069 + z5;                   /* FIX(1.961570560) */
+    z4 = z4 * -3196 + z5;                    /* FIX(0.390180644) */
+    d7 = (t4 + z1 + z3 + R) >> S;
+    d5 = (t5 + z2 + z4 + R) >> S;
+    d3 = (t6 + z2 + z3 + R) >> S;
+    d1 = (t7 + z1 + z4 + R) >> S;
+}
+
+/* libjpeg's quantisation of one coefficient (jcdctmgr.c, forward_DCT): the divisor is 8 q (the transform's scale), the
+ * quotient is rounded half away from zero.  `magic` = dfx_jpeg_divide_magic(8 q): the quotient as the high half of a
+ * 32 x 32 product, exact for every numerator this encoder can produce (numerator * divisor < 2^32; checked
+ * exhaustively in tests/test_jpeg_libjpeg_pin.py). */
+DFX_JPEG_HD inline unsigned dfx_jpeg_divide_magic(unsigned divisor) { return (unsigned)(0x100000000ull / divisor) + 1u; }
+DFX_JPEG_HD inline int dfx_jpeg_quantise(int coef8, unsigned divisor, unsigned magic) {
+    const unsigned n = (unsigned)(coef8 < 0 ? -coef8 : coef8) + (divisor >> 1);
+    const int q = (int)(((unsigned long long)n * magic) >> 32);
+    return coef8 < 0 ? -q : q;
+}
+#endif
 
 #endif /* DFX_JPEG_TABLES_H */

@@ -241,40 +241,37 @@ void put16(vector<uchar> &o, int v) {
     o.push_back((uchar)v);
 }
 
-// Forward DCT of one 8x8 block + quantisation.  c[v][y] is the DCT basis (row v = frequency), rq[v*8+u] the
-// reciprocal quantiser.  coef[v*8+u] in natural order.  Two implementations with the same arithmetic order
-// per output (sum over the 8 inputs in index order): a portable one, and AVX2+FMA intrinsics selected at run
-// time (the encoders of the save stage are the host-side bottleneck once the flows come bounded from the GPU).
-void load_block(const uchar *src, size_t pitch, int valid_w, int valid_h, float blk[8][8]) {
-    for (int y = 0; y < 8; ++y) { // ragged right / bottom edge: replicate the last column / row
+// Forward DCT of one 8x8 block + quantisation: libjpeg's JDCT_ISLOW transform and its quantisation rule
+// (include/dfx_jpeg_tables.h), i.e. the arithmetic behind cv::imencode(".jpg").  coef[v*8+u] in natural order.  Integer
+// arithmetic, so the two forms below — scalar, and eight lines at a time on AVX2 registers where the CPU has them —
+// agree by construction.  Ragged right / bottom edge: the last column / row is replicated, as libjpeg's
+// edge expansion does (jcprepct.c).
+struct QuantTable {
+    unsigned div[64], magic[64]; // 8 q and its reciprocal (dfx_jpeg_divide_magic), natural order
+};
+
+void fdct_quant_scalar(const uchar *src, size_t pitch, int valid_w, int valid_h, const QuantTable &Q, int *coef) {
+    int d[8][8];
+    for (int y = 0; y < 8; ++y) {
         const uchar *row = src + (size_t)std::min(y, valid_h - 1) * pitch;
         for (int x = 0; x < 8; ++x)
-            blk[y][x] = (float)row[std::min(x, valid_w - 1)] - 128.f;
+            d[y][x] = (int)row[std::min(x, valid_w - 1)] - 128;
     }
-}
-
-void fdct_quant_portable(const float blk[8][8], const float (*c)[8], const float *rq, int *coef) {
-    // the very operations of the AVX2 form and of the device encoder: one product, then seven fused multiply-adds in
-    // index order (std::fmaf is exact whether or not the CPU has an FMA unit), so every path gives the same coefficients
-    float t1[8][8]; // t1[v][x] = sum_y c[v][y] * blk[y][x]
-    for (int v = 0; v < 8; ++v)
-        for (int x = 0; x < 8; ++x) {
-            float s = c[v][0] * blk[0][x];
-            for (int y = 1; y < 8; ++y)
-                s = std::fmaf(c[v][y], blk[y][x], s);
-            t1[v][x] = s;
-        }
-    for (int v = 0; v < 8; ++v)
-        for (int u = 0; u < 8; ++u) {
-            float s = c[u][0] * t1[v][0];
-            for (int x = 1; x < 8; ++x)
-                s = std::fmaf(c[u][x], t1[v][x], s);
-            coef[v * 8 + u] = (int)std::lrintf(s * rq[v * 8 + u]);
-        }
+    for (int y = 0; y < 8; ++y)
+        dfx_jpeg_fdct_islow_1d<true>(d[y][0], d[y][1], d[y][2], d[y][3], d[y][4], d[y][5], d[y][6], d[y][7]);
+    for (int x = 0; x < 8; ++x)
+        dfx_jpeg_fdct_islow_1d<false>(d[0][x], d[1][x], d[2][x], d[3][x], d[4][x], d[5][x], d[6][x], d[7][x]);
+    for (int i = 0; i < 64; ++i)
+        coef[i] = dfx_jpeg_quantise(d[i >> 3][i & 7], Q.div[i], Q.magic[i]);
 }
 
 #if defined(__x86_64__)
-__attribute__((target("avx2,fma"))) inline void transpose8(__m256 r[8]) {
+typedef int v8i __attribute__((vector_size(32)));
+
+__attribute__((target("avx2"))) inline void transpose8(v8i v[8]) {
+    __m256 r[8];
+    for (int i = 0; i < 8; ++i)
+        r[i] = _mm256_castsi256_ps((__m256i)v[i]);
     __m256 t0 = _mm256_unpacklo_ps(r[0], r[1]), t1 = _mm256_unpackhi_ps(r[0], r[1]);
     __m256 t2 = _mm256_unpacklo_ps(r[2], r[3]), t3 = _mm256_unpackhi_ps(r[2], r[3]);
     __m256 t4 = _mm256_unpacklo_ps(r[4], r[5]), t5 = _mm256_unpackhi_ps(r[4], r[5]);
@@ -287,49 +284,44 @@ __attribute__((target("avx2,fma"))) inline void transpose8(__m256 r[8]) {
     r[2] = _mm256_permute2f128_ps(s2, s6, 0x20), r[3] = _mm256_permute2f128_ps(s3, s7, 0x20);
     r[4] = _mm256_permute2f128_ps(s0, s4, 0x31), r[5] = _mm256_permute2f128_ps(s1, s5, 0x31);
     r[6] = _mm256_permute2f128_ps(s2, s6, 0x31), r[7] = _mm256_permute2f128_ps(s3, s7, 0x31);
+    for (int i = 0; i < 8; ++i)
+        v[i] = (v8i)_mm256_castps_si256(r[i]);
 }
 
-// out[v] = sum_y c[v][y] * in[y]  (each in[y] / out[v] is a row of 8 lanes)
-__attribute__((target("avx2,fma"))) inline void dct_rows(const __m256 in[8], const float (*c)[8], __m256 out[8]) {
-    for (int v = 0; v < 8; ++v) {
-        __m256 acc = _mm256_mul_ps(_mm256_broadcast_ss(&c[v][0]), in[0]);
-        for (int y = 1; y < 8; ++y)
-            acc = _mm256_fmadd_ps(_mm256_broadcast_ss(&c[v][y]), in[y], acc);
-        out[v] = acc;
+// eight lines at a time: the same integer operations as fdct_quant_scalar on AVX2 registers
+__attribute__((target("avx2"))) void fdct_quant_avx2(const uchar *src, size_t pitch, const QuantTable &Q, int *coef) {
+    v8i r[8]; // r[y] = row y of the block (lane x)
+    const __m256i bias = _mm256_set1_epi32(128);
+    for (int y = 0; y < 8; ++y)
+        r[y] = (v8i)_mm256_sub_epi32(
+            _mm256_cvtepu8_epi32(_mm_loadl_epi64(reinterpret_cast<const __m128i *>(src + (size_t)y * pitch))), bias);
+    transpose8(r); // r[x] = column x (lane y): pass 1 transforms all eight rows at once
+    dfx_jpeg_fdct_islow_1d<true>(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+    transpose8(r); // r[y] = row y (lane u): pass 2 transforms all eight columns at once
+    dfx_jpeg_fdct_islow_1d<false>(r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+    for (int v = 0; v < 8; ++v) { // dfx_jpeg_quantise on eight coefficients: |c| + d/2, high half of the product with magic, sign
+        const __m256i c = (__m256i)r[v];
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(Q.div + 8 * v));
+        const __m256i m = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(Q.magic + 8 * v));
+        const __m256i n = _mm256_add_epi32(_mm256_abs_epi32(c), _mm256_srli_epi32(d, 1));
+        const __m256i even = _mm256_srli_epi64(_mm256_mul_epu32(n, m), 32);                     // lanes 0 2 4 6
+        const __m256i odd = _mm256_mul_epu32(_mm256_srli_epi64(n, 32), _mm256_srli_epi64(m, 32)); // high halves: lanes 1 3 5 7
+        const __m256i q = _mm256_blend_epi32(even, odd, 0xAA);
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(coef + 8 * v), _mm256_sign_epi32(q, c));
     }
 }
-
-__attribute__((target("avx2,fma"))) void fdct_quant_avx2(const uchar *src, size_t pitch, const float (*c)[8],
-                                                          const float *rq, int *coef) {
-    __m256 r[8], t[8];
-    const __m256 bias = _mm256_set1_ps(128.f);
-    for (int y = 0; y < 8; ++y) {
-        const __m128i b = _mm_loadl_epi64(reinterpret_cast<const __m128i *>(src + (size_t)y * pitch));
-        r[y] = _mm256_sub_ps(_mm256_cvtepi32_ps(_mm256_cvtepu8_epi32(b)), bias);
-    }
-    dct_rows(r, c, t); // t[v][x]: vertical frequencies
-    transpose8(t);     // t[x][v]
-    dct_rows(t, c, r); // r[u][v]: both
-    transpose8(r);     // r[v][u]
-    for (int v = 0; v < 8; ++v)
-        _mm256_storeu_si256(reinterpret_cast<__m256i *>(coef + 8 * v),
-                            _mm256_cvtps_epi32(_mm256_mul_ps(r[v], _mm256_loadu_ps(rq + 8 * v)))); // nearest even
-}
-const bool g_has_avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma");
+const bool g_has_avx2 = __builtin_cpu_supports("avx2");
 #endif
 bool g_force_portable = false;
 
-inline void fdct_quant(const uchar *src, size_t pitch, int valid_w, int valid_h, const float (*c)[8], const float *rq,
-                       int *coef) {
+inline void fdct_quant(const uchar *src, size_t pitch, int valid_w, int valid_h, const QuantTable &Q, int *coef) {
 #if defined(__x86_64__)
     if (g_has_avx2 && !g_force_portable && valid_w >= 8 && valid_h >= 8) {
-        fdct_quant_avx2(src, pitch, c, rq, coef);
+        fdct_quant_avx2(src, pitch, Q, coef);
         return;
     }
 #endif
-    float blk[8][8];
-    load_block(src, pitch, valid_w, valid_h, blk);
-    fdct_quant_portable(blk, c, rq, coef);
+    fdct_quant_scalar(src, pitch, valid_w, valid_h, Q, coef);
 }
 
 inline int bit_length(int a) { return a ? 32 - __builtin_clz((unsigned)a) : 0; }
@@ -342,20 +334,18 @@ bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
     if (gray.empty() || gray.type() != CV_8UC1)
         return false;
     uchar q[64];
-    float rq[64];
+    QuantTable Q;
     dfx_jpeg_quantiser(quality, q);
-    for (int i = 0; i < 64; ++i)
-        rq[i] = 1.0f / (float)q[i];
+    for (int i = 0; i < 64; ++i) {
+        Q.div[i] = 8u * q[i];
+        Q.magic[i] = dfx_jpeg_divide_magic(Q.div[i]);
+    }
     struct Tables {
         HuffTable dc, ac;
-        float c[8][8];      // c[u][x] = DCT-II basis, orthonormal
         uchar nat2zig[64];  // position of natural-order coefficient i in the zig-zag scan
         Tables() {
             dc.build(kDcBits, kDcVal);
             ac.build(kAcBits, kAcVal);
-            for (int u = 0; u < 8; ++u)
-                for (int x = 0; x < 8; ++x)
-                    c[u][x] = kDfxJpegDctBasis[u][x];
             for (int k = 0; k < 64; ++k)
                 nat2zig[kZigzag[k]] = (uchar)k;
         }
@@ -389,7 +379,7 @@ bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
     for (int by = 0; by < H; by += 8) {
         for (int bx = 0; bx < W; bx += 8) {
             alignas(32) int coef[64];
-            fdct_quant(gray.ptr<uchar>(by) + bx, gray.step, W - bx, H - by, T.c, rq, coef);
+            fdct_quant(gray.ptr<uchar>(by) + bx, gray.step, W - bx, H - by, Q, coef);
             // DC difference
             const int diff = coef[0] - prev_dc;
             prev_dc = coef[0];

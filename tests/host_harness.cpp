@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "../include/dense_flow.h"
+#include "../include/dfx_jpeg_tables.h"
 #include "../include/utils.h"
 
 extern "C" {
@@ -26,6 +27,21 @@ int hh_encode_jpeg(const uchar *gray, int w, int h, int quality, uchar *out, int
         return -1;
     memcpy(out, buf.data(), buf.size());
     return (int)buf.size();
+}
+
+// dfx_jpeg_quantise (the reciprocal-multiply form both encoders use) against libjpeg's rule written with a plain
+// integer division, for every divisor 8 q (q = 1..255) and every transform output in +-limit: the number of mismatches
+long long hh_jpeg_quantise_mismatches(int limit) {
+    long long bad = 0;
+    for (unsigned q = 1; q <= 255; ++q) {
+        const unsigned d = 8 * q, m = dfx_jpeg_divide_magic(d);
+        for (int c = -limit; c <= limit; ++c) {
+            int t = c < 0 ? -c : c;
+            t = (t + (int)(d >> 1)) / (int)d;
+            bad += dfx_jpeg_quantise(c, d, m) != (c < 0 ? -t : t);
+        }
+    }
+    return bad;
 }
 
 int hh_encode_flow_png(const float *fx, const float *fy, int w, int h, uchar *out, int out_cap) {

@@ -1,7 +1,8 @@
 """Device JPEG encoder (denseflow_amd/csrc/jpeg_kernels.hip, dfx_calc_batch_jpeg): the files must be, byte for byte,
-what the shell's host encoder (src/image_io.cpp: imencodeJpeg — the stand-in for the reference's imencode(".jpg"),
-/root/reference/src/common.cpp:56-57) writes for the same bounded planes, and decode (PIL) to those planes within JPEG
-error.  Integer / byte work: bit-exact."""
+what libjpeg-turbo writes for the same bounded planes — the library behind the reference's imencode(".jpg"),
+/root/reference/src/common.cpp:56-57; live through Pillow, and tests/golden/jpeg_golden.npz — and what the shell's host
+encoder writes (src/image_io.cpp: imencodeJpeg, itself pinned to libjpeg in tests/test_jpeg_libjpeg_pin.py).  Integer /
+byte work: bit-exact."""
 import ctypes as C
 import io
 
@@ -12,6 +13,14 @@ from denseflow_amd.synth import SynthClip
 from tests.test_host_shell import built, harness  # noqa: F401  (fixtures)
 
 pytestmark = pytest.mark.gpu
+
+
+def _libjpeg_file(plane, quality):
+    from PIL import Image
+
+    b = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(plane), "L").save(b, "JPEG", quality=quality)
+    return b.getvalue()
 
 
 def _host_file(harness, plane, quality):
@@ -28,7 +37,7 @@ def _host_file(harness, plane, quality):
                                                       ("tvl1", 224, 224, 5, 95, 3), ("farn", 257, 131, 4, 50, 0),
                                                       ("farn", 64, 64, 3, 100, 0), ("brox", 352, 288, 3, 95, 0),
                                                       ("farn", 1920, 1080, 4, 95, 2), ("farn", 33, 17, 3, 10, 0)])
-def test_files_are_the_host_encoders_byte_for_byte(dfx, harness, algo, w, h, n, quality, batch):
+def test_files_are_libjpegs_and_the_host_encoders_byte_for_byte(dfx, harness, algo, w, h, n, quality, batch):
     from PIL import Image
 
     frames = SynthClip(w, h, 31).frames(n)
@@ -43,6 +52,7 @@ def test_files_are_the_host_encoders_byte_for_byte(dfx, harness, algo, w, h, n, 
             want = _host_file(harness, plane, quality)
             assert got == want, f"{algo} {w}x{h} q{quality} flow {i}: {len(got)} vs {len(want)} bytes"
             assert again == want
+            assert got == _libjpeg_file(plane, quality), f"{algo} {w}x{h} q{quality} flow {i}: not libjpeg's bytes"
             dec = np.array(Image.open(io.BytesIO(got)))
             assert dec.shape == (h, w)
             if quality >= 95:
@@ -101,17 +111,21 @@ def test_submit_form_and_capacity_error(dfx, harness):
 
 
 def test_golden_files(dfx):
-    """tests/golden/jpeg_golden.npz (minted from the host encoder, tests/golden/make_jpeg_golden.py): the device encoder
-    on its own (dfx_encode_jpeg) must write those very bytes — smooth, ragged-edge + saturated, busy planes; q 95 / 50."""
+    """tests/golden/jpeg_golden.npz — files written by libjpeg-turbo (tests/golden/make_jpeg_golden.py): the device
+    encoder on its own (dfx_encode_jpeg) must write those very bytes — smooth, ragged-edge + saturated, busy, noise,
+    flow-like planes down to 1x1; q 95 / 50 / 100 / 10."""
     import os
 
+    from tests.golden.make_jpeg_golden import CASES, QUALITIES
+
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_golden.npz"))
-    for name in ("smooth_96x64", "ragged_45x27", "busy_64x64"):
+    for name in CASES:
         plane = g[name + "_plane"]
         h, w = plane.shape
         with dfx.FlowEngine(w, h, "farn") as eng:
-            for q in (95, 50):
+            for q in QUALITIES:
                 got = eng.encode_jpeg([plane, plane[::-1].copy(), plane], q)
                 want = g[f"{name}_q{q}_file"].tobytes()
                 assert got[0] == want and got[2] == want, (name, q)
-                assert got[1] != want
+                if w * h >= 1000 and q >= 95:
+                    assert got[1] != want  # the flipped plane in between is a different file

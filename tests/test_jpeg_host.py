@@ -66,8 +66,8 @@ def test_assembly_reproduces_the_host_encoders_file(harness, w, h, quality):
 
 
 def test_simd_and_portable_transforms_are_now_bit_identical(harness):
-    """Both host transforms and the device kernel evaluate one product and seven fused multiply-adds per output in the
-    same order (std::fmaf where there is no FMA unit): the files must be IDENTICAL, not just close."""
+    """Both host forms of the transform (eight lines at a time on vector types, and scalar) are libjpeg's integer
+    JDCT_ISLOW: the files must be IDENTICAL, not just close."""
     harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     rng = np.random.default_rng(4)
     for (w, h) in [(64, 64), (70, 45), (257, 131), (9, 17)]:
@@ -83,15 +83,19 @@ def test_simd_and_portable_transforms_are_now_bit_identical(harness):
 
 
 def test_host_encoder_reproduces_the_golden_files(harness):
-    """The shell's encoder against tests/golden/jpeg_golden.npz (the GPU suite holds the device encoder to the same
-    bytes): a change of the shared tables or of the DCT arithmetic of either encoder cannot go unnoticed."""
+    """The shell's encoder against tests/golden/jpeg_golden.npz — files written by libjpeg-turbo itself (Pillow;
+    tests/golden/make_jpeg_golden.py), the library behind the reference's imencode(".jpg").  The GPU suite holds the
+    device encoder to the same bytes."""
     import os
+
+    from tests.golden.make_jpeg_golden import CASES, QUALITIES
 
     harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "jpeg_golden.npz"))
-    for name in ("smooth_96x64", "ragged_45x27", "busy_64x64"):
+    assert bytes(g["libjpeg"]).startswith(b"libjpeg-turbo")
+    for name in CASES:
         plane = np.ascontiguousarray(g[name + "_plane"])
-        for q in (95, 50):
+        for q in QUALITIES:
             for portable in (0, 1):
                 harness.hh_jpeg_force_portable(portable)
                 buf = np.zeros(1 << 20, np.uint8)
