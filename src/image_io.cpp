@@ -417,17 +417,24 @@ bool imencodeJpeg(const Mat &gray, vector<uchar> &out, int quality) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// PNG writer: 8-bit gray or BGR (stored as RGB), per-row None/Sub/Up filter, zlib level 1
+// PNG writer: 8-bit gray or BGR (stored as RGB) — the file cv::imencode(".png") writes (reference src/common.cpp:70).
+// OpenCV's PngEncoder (modules/imgcodecs/src/grfmt_png.cpp, 4.5.2 as the reference's Dockerfile pins it) drives libpng
+// with: every scanline filtered with SUB, zlib level Z_BEST_SPEED, strategy Z_RLE (IMWRITE_PNG_STRATEGY_RLE, its
+// default), no interlace, png_set_bgr.  libpng 1.6 (pngwutil.c) adds: windowBits shrunk for images of <= 16384 filtered
+// bytes (png_deflate_claim), memLevel 8, the zlib header's window field minimised afterwards (optimize_cmf), and the
+// compressed stream cut into IDAT chunks of its 8192-byte buffer.  libpng is a third-party dependency that is not in
+// /root/reference; this restates those published rules on top of the same zlib, and tests/test_png_libpng_pin.py holds
+// it to the bytes the system's libpng16 writes under exactly those calls.
 
 namespace {
 void put32(vector<uchar> &o, unsigned v) {
     o.push_back((uchar)(v >> 24)), o.push_back((uchar)(v >> 16)), o.push_back((uchar)(v >> 8)), o.push_back((uchar)v);
 }
-void chunk(vector<uchar> &o, const char *type, const vector<uchar> &data) {
-    put32(o, (unsigned)data.size());
+void chunk(vector<uchar> &o, const char *type, const uchar *data, size_t n) {
+    put32(o, (unsigned)n);
     const size_t start = o.size();
     o.insert(o.end(), type, type + 4);
-    o.insert(o.end(), data.begin(), data.end());
+    o.insert(o.end(), data, data + n);
     // zlib's CRC-32 (the PNG chunk CRC); a lazily built local table here was a data race between parallel encoders
     put32(o, (unsigned)crc32(0L, o.data() + start, (uInt)(o.size() - start)));
 }
@@ -438,48 +445,67 @@ bool imencodePng(const Mat &img, vector<uchar> &out) {
         return false;
     const int ch = img.channels(), W = img.cols, H = img.rows;
     const size_t rb = (size_t)W * ch;
-    // scanlines in PNG order (RGB), each with the cheapest of the filters None / Sub / Up by libpng's heuristic
-    // (smallest sum of absolute values of the filtered bytes taken as signed)
-    vector<uchar> raw((size_t)H * (rb + 1)), cur(rb), prev(rb, 0), cand(rb);
+    // scanlines in PNG order (RGB), each SUB-filtered: byte i minus the byte one pixel to the left.  libpng drops SUB for
+    // images one pixel wide (png_write_start_row): the same bytes, labelled NONE
+    vector<uchar> raw((size_t)H * (rb + 1));
     for (int y = 0; y < H; ++y) {
         const uchar *r = img.ptr<uchar>(y);
-        if (ch == 1)
-            std::memcpy(cur.data(), r, rb);
-        else
-            for (int x = 0; x < W; ++x)
-                cur[3 * x] = r[3 * x + 2], cur[3 * x + 1] = r[3 * x + 1], cur[3 * x + 2] = r[3 * x];
         uchar *dst = raw.data() + (size_t)y * (rb + 1);
-        unsigned long best = ~0ul;
-        for (int f = 0; f < 3; ++f) {
-            unsigned long cost = 0;
-            for (size_t i = 0; i < rb; ++i) {
-                const uchar pred = f == 0 ? 0 : f == 1 ? (i >= (size_t)ch ? cur[i - ch] : 0) : prev[i];
-                const uchar v = (uchar)(cur[i] - pred);
-                cand[i] = v;
-                cost += v < 128 ? v : 256 - v;
-            }
-            if (cost < best) {
-                best = cost;
-                dst[0] = (uchar)f;
-                std::memcpy(dst + 1, cand.data(), rb);
-            }
+        *dst++ = W == 1 ? 0 : 1;
+        if (ch == 1) {
+            dst[0] = r[0];
+            for (size_t i = 1; i < rb; ++i)
+                dst[i] = (uchar)(r[i] - r[i - 1]);
+        } else {
+            for (int x = 0; x < W; ++x)
+                for (int k = 0; k < 3; ++k) // output channel k = input channel 2 - k (png_set_bgr)
+                    dst[3 * x + k] = (uchar)(r[3 * x + 2 - k] - (x ? r[3 * x - 1 - k] : 0));
         }
-        prev.swap(cur);
     }
-    // zlib stream, level 1 (cv::imencode's default PNG compression level is 1 as well)
-    uLongf zlen = compressBound((uLong)raw.size());
-    vector<uchar> z(zlen);
-    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 1) != Z_OK)
+    // libpng's png_deflate_claim: the window only as large as the data needs (images of <= 16384 filtered bytes)
+    int window_bits = 15;
+    if (raw.size() <= 16384) {
+        unsigned half_window = 1u << (window_bits - 1);
+        while (raw.size() + 262 <= half_window) {
+            half_window >>= 1;
+            --window_bits;
+        }
+    }
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, Z_BEST_SPEED, Z_DEFLATED, window_bits, 8, Z_RLE) != Z_OK)
         return false;
-    z.resize(zlen);
+    vector<uchar> z(deflateBound(&zs, (uLong)raw.size()) + 64);
+    zs.next_in = raw.data(), zs.avail_in = (uInt)raw.size();
+    zs.next_out = z.data(), zs.avail_out = (uInt)z.size();
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t zlen = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END)
+        return false;
+    // libpng's optimize_cmf: the smallest window field the data size allows, header check bits redone
+    if (raw.size() <= 16384 && (z[0] & 0x0f) == 8 && (z[0] & 0xf0) <= 0x70) {
+        unsigned cinfo = z[0] >> 4, half_window = 1u << (cinfo + 7);
+        if (raw.size() <= half_window) {
+            do {
+                half_window >>= 1;
+                --cinfo;
+            } while (cinfo > 0 && raw.size() <= half_window);
+            z[0] = (uchar)((z[0] & 0x0f) | (cinfo << 4));
+            unsigned t = z[1] & 0xe0;
+            t += 0x1f - ((z[0] << 8) + t) % 0x1f;
+            z[1] = (uchar)t;
+        }
+    }
     out.clear();
     const uchar sig[] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     out.insert(out.end(), sig, sig + 8);
     vector<uchar> ihdr;
     put32(ihdr, (unsigned)W), put32(ihdr, (unsigned)H);
     ihdr.push_back(8), ihdr.push_back(ch == 1 ? 0 : 2), ihdr.push_back(0), ihdr.push_back(0), ihdr.push_back(0);
-    chunk(out, "IHDR", ihdr);
-    chunk(out, "IDAT", z);
-    chunk(out, "IEND", vector<uchar>());
+    chunk(out, "IHDR", ihdr.data(), ihdr.size());
+    for (size_t off = 0; off < zlen; off += 8192) // libpng's zbuffer: one IDAT per 8192 bytes of compressed stream
+        chunk(out, "IDAT", z.data() + off, std::min<size_t>(8192, zlen - off));
+    chunk(out, "IEND", nullptr, 0);
     return true;
 }

@@ -44,6 +44,17 @@ long long hh_jpeg_quantise_mismatches(int limit) {
     return bad;
 }
 
+// imencodePng of an 8-bit gray (ch = 1) or BGR (ch = 3) image
+int hh_encode_png(const uchar *px, int w, int h, int ch, uchar *out, int out_cap) {
+    Mat m(Size(w, h), ch == 1 ? CV_8UC1 : CV_8UC3);
+    memcpy(m.data(), px, (size_t)w * h * ch);
+    vector<uchar> buf;
+    if (!imencodePng(m, buf) || (int)buf.size() > out_cap)
+        return -1;
+    memcpy(out, buf.data(), buf.size());
+    return (int)buf.size();
+}
+
 int hh_encode_flow_png(const float *fx, const float *fy, int w, int h, uchar *out, int out_cap) {
     Mat a(Size(w, h), CV_32FC1), b(Size(w, h), CV_32FC1);
     memcpy(a.data(), fx, sizeof(float) * w * h);
