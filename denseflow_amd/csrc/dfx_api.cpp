@@ -281,6 +281,9 @@ struct BatchPlan {
 int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_pitch, const uint8_t *d_frames,
                     size_t d_pitch, size_t d_frame_stride, int n_frames, int step, const OutSpec &out,
                     unsigned long long *ticket) {
+    // dfx_next_segments applies to this call only, whatever becomes of it
+    std::vector<int> seg;
+    seg.swap(c->next_segments);
     if (ticket)
         *ticket = 0;
     else
@@ -288,24 +291,58 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     if (n_frames < 0 || step == 0)
         return dfx_fail(c, DFX_ERR_INVALID, "n_frames must be >= 0 and step non-zero");
     const int astep = std::abs(step);
-    const int M = std::max(n_frames - astep, 0); // src/denseflow_gpu.cpp:307-308
+    // The FlowBuffer's pairs as (frame a, frame b), frame ids counted over the whole buffer.  One clip: pair i is
+    // (i, i + step) for step > 0, (i - step, i) otherwise, M = max(N - |step|, 0) of them (src/denseflow_gpu.cpp:307-316).
+    // Several clips joined (dfx_next_segments): the same rule inside every clip, no pair across a clip boundary.
+    if (seg.empty())
+        seg.push_back(n_frames);
+    {
+        long long total = 0;
+        for (int n : seg) {
+            if (n < 0)
+                return dfx_fail(c, DFX_ERR_INVALID, "dfx_next_segments: negative clip length");
+            total += n;
+        }
+        if (total != n_frames)
+            return dfx_fail(c, DFX_ERR_INVALID, "dfx_next_segments: the clip lengths do not add up to n_frames");
+    }
+    std::vector<int> pair_lo, pair_hi; // the two frames of pair i: lo < hi (which of them is `a` depends on the step's sign)
+    {
+        int off = 0;
+        for (int n : seg) {
+            for (int i = 0; i + astep < n; ++i) {
+                pair_lo.push_back(off + i);
+                pair_hi.push_back(off + i + astep);
+            }
+            off += n;
+        }
+    }
+    const int M = (int)pair_lo.size();
     if (M == 0)
         return DFX_OK;
     HIPCHK(c, hipSetDevice(c->device));
     AlgoEngine *E = c->engine;
     int B = E->batch();
-    int rc = E->ensure_frame_slots(B + astep);
+    // frames that one batch of B pairs can need: B + |step| inside one clip, |step| more for every clip boundary it spans
+    auto frames_needed = [&](int b) {
+        int need = 0;
+        for (int i0 = 0; i0 < M; i0 += b)
+            need = std::max(need, pair_hi[std::min(i0 + b, M) - 1] - pair_lo[i0] + 1);
+        return need;
+    };
+    int F_need = std::max(frames_needed(B), std::min(B, M) + astep);
+    int rc = E->ensure_frame_slots(F_need);
     if (rc != DFX_OK)
         return rc;
     const bool host_mode = frames != nullptr;
     // float flows land in the caller's device array, or in a staging set when they are copied to the host
     // or only feed the bounding kernel
     const bool prep = c->prepares(); // inputs are source-format frames: convert / resize them on the device first
-    rc = ensure_staging(c, (host_mode || prep) ? B + astep : 0, (host_mode || out.quantized) ? B : 0);
+    rc = ensure_staging(c, (host_mode || prep) ? F_need : 0, (host_mode || out.quantized) ? B : 0);
     if (rc != DFX_OK)
         return rc;
     if (prep && host_mode) {
-        rc = ensure_src_staging(c, B + astep);
+        rc = ensure_src_staging(c, F_need);
         if (rc != DFX_OK)
             return rc;
     }
@@ -328,10 +365,10 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     const size_t out_pb = out.quantized ? 2 * plane : plane * 8; // bytes per pair leaving the device
     // Decided per direction: a 224x224 frame is 50 KB (gathered), but its float flow is 401 KB — one direct copy per
     // flow (~10 us of driver time) is cheaper than a second pass of host memcpy over 120 MB per clip.
-    const bool bounce_in = host_mode && in_fb <= (256u << 10) && (size_t)(B + astep) * in_fb <= (256u << 20);
+    const bool bounce_in = host_mode && in_fb <= (256u << 10) && (size_t)F_need * in_fb <= (256u << 20);
     const bool bounce = !out.jpeg && bounce_in && out_pb <= (256u << 10) && (size_t)B * out_pb <= (256u << 20); // results
     if (bounce_in) {
-        rc = ensure_bounce(c, (size_t)(B + astep) * in_fb, bounce ? (size_t)B * out_pb : 0);
+        rc = ensure_bounce(c, (size_t)F_need * in_fb, bounce ? (size_t)B * out_pb : 0);
         if (rc != DFX_OK)
             return rc;
     } else if (host_mode && M <= B && M >= 32) {
@@ -344,8 +381,8 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     c->h_slots.resize(F);
     c->h_pairs.resize(B);
 
-    // Frames [i0, i0+nb+astep) must be resident for a batch; earlier batches already prepared the ids below
-    // their own end.  Frame id f lives in slot f % F; F >= nb + astep, so a batch never evicts what it needs.
+    // Frames [lo of its first pair, hi of its last pair] must be resident for a batch; earlier batches already prepared
+    // the ids below their own end.  Frame id f lives in slot f % F; F >= that range, so a batch never evicts what it needs.
     std::vector<BatchPlan> plan;
     {
         long long built = 0;
@@ -353,8 +390,8 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             BatchPlan p;
             p.i0 = i0;
             p.nb = std::min(B, M - i0);
-            const long long need_end = (long long)i0 + p.nb + astep;
-            p.first_new = std::max<long long>(built, i0);
+            const long long need_end = (long long)pair_hi[i0 + p.nb - 1] + 1;
+            p.first_new = std::max<long long>(built, pair_lo[i0]);
             p.n_new = (int)std::max<long long>(need_end - p.first_new, 0);
             built = std::max(built, need_end);
             plan.push_back(p);
@@ -518,18 +555,25 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 if (rc != DFX_OK)
                     return rc;
             }
-            if (k + 1 < plan.size()) {
+            // Host work that can run beside this thread driving batch k (the TVL1 engine polls the device inside
+            // run_pairs), on a helper thread: hand the results of batch k-1 over (rows to the caller's buffers / JPEG
+            // files assembled; its download was enqueued just above and is a fraction of a batch's compute time), and — for
+            // small frames — gather the frames of batch k+1 into the page-locked bounce buffer and send them up: 2048
+            // frames of 224 x 224 are 100 MB of host memcpy, 6 % of their batch's compute time when the GPU waits for it.
+            const bool hand_over = (bounce || out.jpeg) && k >= 1;
+            const bool up_next = k + 1 < plan.size();
+            if (up_next && !bounce_in) { // large frames: a few asynchronous copies to enqueue, nothing to gather
                 rc = upload(k + 1);
                 if (rc != DFX_OK)
                     return rc;
             }
-            if ((bounce || out.jpeg) && k >= 1) {
-                // host work on the results of batch k-1 (hand the rows over / assemble the JPEG files) on a helper thread
-                // while this thread drives batch k (the TVL1 engine polls the device inside run_pairs): its download was
-                // enqueued just above and is a fraction of a batch's compute time
-                post.start([&, k] {
+            if (hand_over || (up_next && bounce_in)) {
+                post.start([&, k, hand_over, up_next] {
                     (void)hipSetDevice(c->device);
-                    return scatter(k - 1);
+                    int r = hand_over ? scatter(k - 1) : DFX_OK;
+                    if (r == DFX_OK && up_next && bounce_in)
+                        r = upload(k + 1);
+                    return r;
                 });
             }
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_h2d[par(k)], 0));
@@ -560,13 +604,11 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             if (rc != DFX_OK)
                 return rc;
         }
-        // pair i: a = (step>0 ? i : i-step), b = (step>0 ? i+step : i)   (src/denseflow_gpu.cpp:315-316)
+        // pair i of a clip: a = (step>0 ? i : i-step), b = (step>0 ? i+step : i)   (src/denseflow_gpu.cpp:315-316)
         for (int j = 0; j < p.nb; ++j) {
             const int i = p.i0 + j;
-            const int a = step > 0 ? i : i - step;
-            const int b = step > 0 ? i + step : i;
-            c->h_pairs[j].frame_a = a % F;
-            c->h_pairs[j].frame_b = b % F;
+            c->h_pairs[j].frame_a = (step > 0 ? pair_lo[i] : pair_hi[i]) % F;
+            c->h_pairs[j].frame_b = (step > 0 ? pair_hi[i] : pair_lo[i]) % F;
         }
         const bool staged = host_mode || out.quantized;
         float *dst = staged ? c->d_flow_out[par(k)] : out.d_flows + (size_t)p.i0 * out.d_flow_stride;
@@ -1081,6 +1123,22 @@ size_t dfx_jpeg_capacity(dfx_handle h) {
     // BEFORE stuffing) is far outside what flow images produce; such a FlowBuffer fails with DFX_ERR_INVALID /
     // DFX_ERR_UNSUPPORTED and the caller encodes its 8-bit planes (dfx_calc_batch_u8) itself.
     return (size_t)h->W * h->H + 4096;
+}
+
+int dfx_next_segments(dfx_handle h, const int *seg_frames, int n_segments) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    h->next_segments.clear();
+    if (n_segments < 0 || (n_segments > 0 && !seg_frames))
+        return dfx_fail(h, DFX_ERR_INVALID, "dfx_next_segments: NULL clip lengths");
+    for (int i = 0; i < n_segments; ++i) {
+        if (seg_frames[i] < 0) {
+            h->next_segments.clear();
+            return dfx_fail(h, DFX_ERR_INVALID, "dfx_next_segments: negative clip length");
+        }
+        h->next_segments.push_back(seg_frames[i]);
+    }
+    return DFX_OK;
 }
 
 int dfx_wait(dfx_handle h, uint64_t ticket) {

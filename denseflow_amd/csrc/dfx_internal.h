@@ -25,6 +25,11 @@
 //     account       - fold the finished batch into dfx_stats (after the stream is synchronised)
 struct dfx_context;
 
+// Automatic batch (dfx_params.max_batch = 0): as many pairs as 256 Mpx of level-0 pixels hold (129 at 1080p), at most
+// this many.  Small frames reach it: 2048 pairs of 224 x 224 are 103 Mpx — 0.4 of the 1080p batch — and a FlowBuffer
+// only fills such a batch when it joins several clips (dfx_next_segments).
+constexpr long long DFX_MAX_BATCH = 2048;
+
 class AlgoEngine {
   public:
     virtual ~AlgoEngine() {}
@@ -108,6 +113,7 @@ struct dfx_context {
 
     // Batches are numbered across calls: staging set, bounce buffer and event of batch q are those of parity q & 1.
     unsigned long long batch_seq = 0;
+    std::vector<int> next_segments; // dfx_next_segments: clip lengths of the NEXT FlowBuffer (consumed by that call)
     // Deferred tails of dfx_submit_*: the last download of a FlowBuffer (and, for small frames, the hand-over from
     // the bounce buffer to the caller's buffers) completes on a helper thread while the next FlowBuffer is issued.
     // A tail stays registered in `tails` until its worker has FINISHED (done, set under tails_mtx): whoever asks about

@@ -159,7 +159,7 @@ int Tvl1Engine::create() {
     B = p.max_batch;
     if (B <= 0) {
         const long long px0 = (long long)c->W * c->H;
-        B = (int)std::max<long long>(1, std::min<long long>(512, (256LL << 20) / std::max<long long>(px0, 1)));
+        B = (int)std::max<long long>(1, std::min<long long>(DFX_MAX_BATCH, (256LL << 20) / std::max<long long>(px0, 1)));
     }
     size_t free_b = 0, total_b = 0;
     HIPCHK(c, hipMemGetInfo(&free_b, &total_b));

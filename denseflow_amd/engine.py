@@ -180,6 +180,8 @@ def load_library():
     L.dfx_encode_jpeg.restype = i
     L.dfx_jpeg_capacity.argtypes = [vp]
     L.dfx_jpeg_capacity.restype = sz
+    L.dfx_next_segments.argtypes = [vp, C.POINTER(C.c_int), i]
+    L.dfx_next_segments.restype = i
     L.dfx_wait.argtypes = [vp, C.c_uint64]
     L.dfx_wait.restype = i
     L.dfx_calc_batch_u8_device.argtypes = [vp, vp, sz, sz, i, i, C.c_double, C.c_double, vp, vp, sz, sz]
@@ -313,6 +315,27 @@ class FlowEngine:
                                                       int(src_height), int(channels), int(n), d_gray_ptr, gray_pitch,
                                                       gray_frame_stride))
 
+    # -- several short clips in one FlowBuffer (dfx_next_segments) ------------------------------------------
+    def next_segments(self, seg_frames):
+        """The NEXT calc_optflows* / submit_optflows call carries len(seg_frames) clips back to back, clip s being
+        seg_frames[s] consecutive frames; pairs are formed inside each clip only (outputs in clip order)."""
+        self._pending_seg = [int(x) for x in seg_frames]
+
+    def _num_pairs(self, n: int, step: int) -> int:
+        seg, self._pending_seg = getattr(self, "_pending_seg", None), None
+        self._armed_seg = None
+        if seg is None:
+            return max(n - abs(step), 0)
+        if sum(seg) != n or min(seg, default=0) < 0:
+            raise ValueError("segment lengths must be >= 0 and add up to the number of frames")
+        self._armed_seg = seg
+        return sum(max(x - abs(step), 0) for x in seg)
+
+    def _arm(self):  # right in front of the library call the declaration is meant for
+        seg, self._armed_seg = getattr(self, "_armed_seg", None), None
+        if seg is not None:
+            self._check(self._L.dfx_next_segments(self._h, (C.c_int * max(len(seg), 1))(*seg), len(seg)))
+
     # -- the hot path ------------------------------------------------------------------------
     def calc(self, frame_a: np.ndarray, frame_b: np.ndarray) -> np.ndarray:
         """alg->calc(a, b): one (H, W, 2) float32 flow, channel 0 = u (x), 1 = v (y)."""
@@ -329,7 +352,7 @@ class FlowEngine:
         """The loop of DenseFlow::calc_optflows_imp (src/denseflow_gpu.cpp:307-342) for one FlowBuffer."""
         frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
         n = len(frames)
-        m = max(n - abs(step), 0)
+        m = self._num_pairs(n, step)
         flows = [np.empty((self.height, self.width, 2), dtype=np.float32) for _ in range(m)]
         if m == 0:
             return flows
@@ -338,6 +361,7 @@ class FlowEngine:
                 raise ValueError("frame shape does not match the engine")
         fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
         op = (C.c_void_p * m)(*[f.ctypes.data for f in flows])
+        self._arm()
         self._check(self._L.dfx_calc_batch(self._h, fp, frames[0].strides[0], n, int(step), op, self.width * 8))
         return flows
 
@@ -348,7 +372,7 @@ class FlowEngine:
         must be kept alive by the caller until then."""
         frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
         n = len(frames)
-        m = max(n - abs(step), 0)
+        m = self._num_pairs(n, step)
         for f in frames:
             if f.shape != self._frame_shape():
                 raise ValueError("frame shape does not match the engine")
@@ -358,12 +382,14 @@ class FlowEngine:
         if bound is None:
             flows = [np.empty((self.height, self.width, 2), dtype=np.float32) for _ in range(m)]
             op = (C.c_void_p * max(m, 1))(*[f.ctypes.data for f in flows])
+            self._arm()
             self._check(self._L.dfx_submit_batch(self._h, fp, pitch, n, int(step), op, self.width * 8, C.byref(t)))
             return t.value, flows
         img_x = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
         img_y = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
         xp = (C.c_void_p * max(m, 1))(*[f.ctypes.data for f in img_x])
         yp = (C.c_void_p * max(m, 1))(*[f.ctypes.data for f in img_y])
+        self._arm()
         self._check(self._L.dfx_submit_batch_u8(self._h, fp, pitch, n, int(step), -float(bound), float(bound), xp, yp,
                                                 self.width, C.byref(t)))
         return t.value, (img_x, img_y)
@@ -374,6 +400,8 @@ class FlowEngine:
     def calc_optflows_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,
                              d_flows_ptr: int, flow_stride_floats: int):
         """Frames and flows already resident in HBM (raw device pointers, e.g. torch .data_ptr())."""
+        self._num_pairs(n_frames, step)
+        self._arm()
         self._check(self._L.dfx_calc_batch_device(self._h, d_frames_ptr, pitch, frame_stride, n_frames, int(step),
                                                   d_flows_ptr, flow_stride_floats))
 
@@ -385,7 +413,7 @@ class FlowEngine:
         [-bound, bound]; pass `lower` for an asymmetric interval [lower, bound]."""
         frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
         n = len(frames)
-        m = max(n - abs(step), 0)
+        m = self._num_pairs(n, step)
         img_x = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
         img_y = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
         if m == 0:
@@ -397,6 +425,7 @@ class FlowEngine:
         fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
         xp = (C.c_void_p * m)(*[f.ctypes.data for f in img_x])
         yp = (C.c_void_p * m)(*[f.ctypes.data for f in img_y])
+        self._arm()
         self._check(self._L.dfx_calc_batch_u8(self._h, fp, frames[0].strides[0], n, int(step), lo, float(bound), xp,
                                               yp, self.width))
         return img_x, img_y
@@ -406,7 +435,7 @@ class FlowEngine:
         `bytes`, the flow_x and flow_y JPEG files (bounded to [-bound, bound], quality like cv::imencode)."""
         frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
         n = len(frames)
-        m = max(n - abs(step), 0)
+        m = self._num_pairs(n, step)
         if m == 0:
             return [], []
         for f in frames:
@@ -417,6 +446,7 @@ class FlowEngine:
         by = [np.empty(cap, np.uint8) for _ in range(m)]
         sx, sy = (C.c_uint32 * m)(), (C.c_uint32 * m)()
         fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        self._arm()
         self._check(self._L.dfx_calc_batch_jpeg(self._h, fp, frames[0].strides[0], n, int(step), -float(bound),
                                                 float(bound), int(quality), (C.c_void_p * m)(*[b.ctypes.data for b in bx]),
                                                 (C.c_void_p * m)(*[b.ctypes.data for b in by]), cap, sx, sy))

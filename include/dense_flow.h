@@ -58,15 +58,23 @@ class FlowBufferQueue {
     void push(FlowBuffer b, bool is_final);
     // pops one buffer; *was_final tells the consumer that no further buffer will ever arrive
     FlowBuffer pop(bool *was_final);
+    // the same without waiting: false when nothing is queued right now
+    bool try_pop(FlowBuffer &out, bool *was_final);
+    // Short clips: the reference's bound of `maxsize` buffers starves a consumer that joins several of them into one
+    // device batch.  With a byte budget the queue also accepts a buffer while fewer than `bytes` bytes (and fewer than
+    // `hard_max` buffers) are queued; large FlowBuffers stay bounded by `maxsize` alone.
+    void set_byte_budget(size_t bytes, size_t hard_max) { byte_budget_ = bytes, hard_max_ = hard_max; }
     // a stage died: producers stop blocking, consumers see an empty final buffer
     void close();
     size_t size();
 
   private:
     size_t maxsize_;
+    size_t byte_budget_ = 0, hard_max_ = 0, bytes_ = 0;
     mutex mtx_;
     condition_variable not_full_, not_empty_;
     queue<std::pair<FlowBuffer, bool>> q_;
+    queue<size_t> q_bytes_;
     bool closed_ = false;
 };
 
@@ -121,10 +129,13 @@ class DenseFlow {
     // the FlowBuffer whose last download is still in flight (dfx_submit_batch*), and whether the buffer being
     // processed is the last of the run
     struct PendingFlows {
-        FlowBuffer flows;
-        uint64_t ticket;
-        bool is_final;
-        dfx_handle handle; // the engine the ticket belongs to (nullptr: nothing to wait for)
+        vector<FlowBuffer> flows; // one result per FlowBuffer of the group that was submitted together, in order
+        uint64_t ticket = 0;
+        bool is_final = false;
+        dfx_handle handle = nullptr; // the engine the ticket belongs to (nullptr: nothing to wait for)
+        // device JPEG: the file sizes of the whole group, written by the library until the ticket is collected; the
+        // collector hands every FlowBuffer its slice (FlowBuffer::Encoded::size_x / size_y)
+        vector<uint32_t> size_x, size_y;
     };
     queue<std::unique_ptr<PendingFlows>> pending_q_; // submitted, tails not yet collected (collect_flows)
     mutex pending_mtx_;
@@ -133,6 +144,10 @@ class DenseFlow {
     bool pending_closed_ = false;
     string pending_error_;
     bool flows_final_ = false;
+    // Short FlowBuffers of one geometry (a list of small clips, BASELINE configs[3]) that are already waiting are joined
+    // into ONE library call (dfx_next_segments): the same flows, fuller device batches.  DF_NO_JOIN=1 disables it.
+    bool join_short_ = true;
+    void submit_group(vector<FlowBuffer> &group, const string &algorithm, int step, bool verbose);
     void collect_flows();
     void enqueue_pending(std::unique_ptr<PendingFlows> p);
 

@@ -34,13 +34,42 @@ static double trace_ms() {
 
 // ------------------------------------------------------------------------------------------------ queue
 
+static size_t flowbuffer_bytes(const FlowBuffer &b) {
+    size_t n = 0;
+    for (const Mat &m : b.item_data)
+        n += (size_t)m.rows * m.step;
+    if (b.encoded)
+        for (uint32_t s : b.encoded->size_x)
+            n += 2 * (size_t)s;
+    return n;
+}
+
 void FlowBufferQueue::push(FlowBuffer b, bool is_final) {
     unique_lock<mutex> lock(mtx_);
-    not_full_.wait(lock, [&] { return closed_ || q_.size() < maxsize_; });
+    not_full_.wait(lock, [&] {
+        return closed_ || q_.size() < maxsize_ || (bytes_ < byte_budget_ && q_.size() < hard_max_);
+    });
     if (closed_)
         return;
+    const size_t nb = flowbuffer_bytes(b);
+    bytes_ += nb;
+    q_bytes_.push(nb);
     q_.emplace(std::move(b), is_final);
     not_empty_.notify_all();
+}
+
+bool FlowBufferQueue::try_pop(FlowBuffer &out, bool *was_final) {
+    unique_lock<mutex> lock(mtx_);
+    if (q_.empty())
+        return false;
+    std::pair<FlowBuffer, bool> item = std::move(q_.front());
+    q_.pop();
+    bytes_ -= q_bytes_.front();
+    q_bytes_.pop();
+    not_full_.notify_all();
+    *was_final = item.second;
+    out = std::move(item.first);
+    return true;
 }
 
 void FlowBufferQueue::close() {
@@ -64,6 +93,8 @@ FlowBuffer FlowBufferQueue::pop(bool *was_final) {
     }
     std::pair<FlowBuffer, bool> item = std::move(q_.front());
     q_.pop();
+    bytes_ -= q_bytes_.front();
+    q_bytes_.pop();
     not_full_.notify_all();
     *was_final = item.second;
     return std::move(item.first);
@@ -81,6 +112,10 @@ DenseFlow::DenseFlow(vector<path> video_paths, vector<path> output_dirs, string 
     device_bounding = this->save_type == "jpg" && !std::getenv("DF_HOST_BOUND");
     device_jpeg = device_bounding && !std::getenv("DF_HOST_JPEG");
     device_resize = !std::getenv("DF_HOST_RESIZE");
+    join_short_ = !std::getenv("DF_NO_JOIN");
+    // short clips: let a few of them queue up so that the flow stage can join them (large FlowBuffers stay at 3 per queue)
+    frames_gray_queue.set_byte_budget(256u << 20, 48);
+    flows_queue.set_byte_budget(256u << 20, 48);
     const char *et = std::getenv("DF_ENCODE_THREADS");
     int hw = (int)std::thread::hardware_concurrency();
     // a container CPU quota (cgroup v2 cpu.max) is the real core count: the MI355X boxes of this pool show 256
@@ -369,7 +404,16 @@ void DenseFlow::collect_flows() {
             frames_gray_queue.close();
             flows_queue.close();
         } else {
-            flows_queue.push(std::move(p->flows), fin);
+            size_t off = 0; // device JPEG: every FlowBuffer of the group gets its slice of the file sizes
+            for (FlowBuffer &fb : p->flows)
+                if (fb.encoded) {
+                    const size_t m = fb.encoded->size_x.size();
+                    std::copy(p->size_x.begin() + off, p->size_x.begin() + off + m, fb.encoded->size_x.begin());
+                    std::copy(p->size_y.begin() + off, p->size_y.begin() + off + m, fb.encoded->size_y.begin());
+                    off += m;
+                }
+            for (size_t g = 0; g < p->flows.size(); ++g)
+                flows_queue.push(std::move(p->flows[g]), fin && g + 1 == p->flows.size());
         }
         {
             unique_lock<mutex> lock(pending_mtx_);
@@ -427,96 +471,146 @@ void DenseFlow::prepare_engine(const string &algorithm, const Size &sz) {
 void DenseFlow::calc_optflows_imp(const FlowBuffer &frames_gray, const string &algorithm, int step, bool verbose,
                                   Stream &stream) {
     (void)stream;
+    vector<FlowBuffer> group(1, frames_gray);
+    submit_group(group, algorithm, step, verbose);
+}
+
+// calc_optflows_imp for a GROUP of FlowBuffers of one geometry (normally one).  Several short clips are one library call
+// (dfx_next_segments: pairs inside every clip only) so that the device batches are fuller than one clip's pairs; every
+// FlowBuffer still gets its own result, in order, with its own output_dir / base_start / last_buffer.
+void DenseFlow::submit_group(vector<FlowBuffer> &group, const string &algorithm, int step, bool verbose) {
     const bool is_final = flows_final_;
-    const int N = (int)frames_gray.item_data.size();
-    const int M = std::max(N - std::abs(step), 0);
-    vector<Mat> flows(M);
-    uint64_t ticket = 0;
-    std::shared_ptr<FlowBuffer::Encoded> encoded;
+    const int astep = std::abs(step);
+    vector<int> seg, m_of;
+    int N = 0, M = 0;
+    const Mat *first = nullptr;
+    for (const FlowBuffer &fb : group) {
+        const int n = (int)fb.item_data.size();
+        seg.push_back(n);
+        m_of.push_back(std::max(n - astep, 0));
+        N += n, M += m_of.back();
+        if (!first && n > 0)
+            first = &fb.item_data[0];
+    }
+    std::unique_ptr<PendingFlows> pend(new PendingFlows());
+    pend->is_final = is_final;
+    vector<vector<Mat>> flows(group.size());
+    vector<std::shared_ptr<FlowBuffer::Encoded>> encoded(group.size());
     if (M > 0) {
-        const Size in_sz = frames_gray.item_data[0].size();
-        const Size sz = frames_gray.target.width > 0 ? frames_gray.target : in_sz; // size of the flows
-        // One pitch and one source format describe the whole FlowBuffer: every frame must have the first one's
-        // geometry (the reference resizes frame by frame, :166-170, so mixed-size image directories work there;
-        // here they would be read out of bounds).
-        for (int i = 1; i < N; ++i) {
-            const Mat &f = frames_gray.item_data[i];
-            if (!(f.size() == in_sz) || f.step != frames_gray.item_data[0].step || f.type() != CV_8UC1)
-                throw std::runtime_error("frames of one FlowBuffer differ in size (" + std::to_string(f.cols) + "x" +
-                                         std::to_string(f.rows) + " after " + std::to_string(in_sz.width) + "x" +
-                                         std::to_string(in_sz.height) + ")");
-        }
-        TRACE("calc: %d frames -> %d flows, %dx%d, algorithm %s", N, M, sz.width, sz.height, algorithm.c_str());
+        const Size in_sz = first->size();
+        Size target;
+        for (const FlowBuffer &fb : group)
+            if (!fb.item_data.empty())
+                target = fb.target;
+        const Size sz = target.width > 0 ? target : in_sz; // size of the flows
+        // One pitch and one source format describe the whole call: every frame must have the first one's geometry (the
+        // reference resizes frame by frame, :166-170, so mixed-size image directories work there; here they would be
+        // read out of bounds).
+        vector<const uint8_t *> in;
+        in.reserve(N);
+        for (const FlowBuffer &fb : group)
+            for (const Mat &f : fb.item_data) {
+                if (!(f.size() == in_sz) || f.step != first->step || f.type() != CV_8UC1)
+                    throw std::runtime_error("frames of one FlowBuffer differ in size (" + std::to_string(f.cols) + "x" +
+                                             std::to_string(f.rows) + " after " + std::to_string(in_sz.width) + "x" +
+                                             std::to_string(in_sz.height) + ")");
+                in.push_back(f.ptr<uint8_t>());
+            }
+        TRACE("calc: %d frames of %d FlowBuffer(s) -> %d flows, %dx%d, algorithm %s", N, (int)group.size(), M, sz.width,
+              sz.height, algorithm.c_str());
         prepare_engine(algorithm, sz); // sized per video; reused across its FlowBuffers (usually created already: engine_hint)
         // cv::resize of load_frames_batch (:169) on the device: source-size frames go up, the engine resizes
         if (dfx_set_source_format(dfx_, sz == in_sz ? 0 : in_sz.width, sz == in_sz ? 0 : in_sz.height, 1) != DFX_OK)
             throw std::runtime_error(dfx_last_error(dfx_));
-        vector<const uint8_t *> in(N);
-        for (int i = 0; i < N; ++i)
-            in[i] = frames_gray.item_data[i].ptr<uint8_t>();
+        auto declare = [&] { // more than one clip in this call: pairs never cross a clip boundary
+            if (group.size() > 1 && dfx_next_segments(dfx_, seg.data(), (int)seg.size()) != DFX_OK)
+                throw std::runtime_error(dfx_last_error(dfx_));
+        };
+        uint64_t ticket = 0;
         bool encoded_on_device = false;
         if (device_jpeg) {
             // encodeFlowMap as a whole (src/common.cpp:48-64) happens on the device: convertFlowToImage(-bound, bound)
             // and both imencode(".jpg") — complete files come back, ~0.1 of the planes' bytes
             const size_t cap = dfx_jpeg_capacity(dfx_);
-            encoded = std::make_shared<FlowBuffer::Encoded>();
-            encoded->size_x.assign(M, 0u), encoded->size_y.assign(M, 0u);
-            vector<uint8_t *> out_x(M), out_y(M);
-            for (int i = 0; i < M; ++i) {
-                encoded->x.emplace_back(new uchar[cap]);
-                encoded->y.emplace_back(new uchar[cap]);
-                out_x[i] = encoded->x[i].get();
-                out_y[i] = encoded->y[i].get();
+            pend->size_x.assign(M, 0u), pend->size_y.assign(M, 0u);
+            vector<uint8_t *> out_x, out_y;
+            for (size_t g = 0; g < group.size(); ++g) {
+                if (m_of[g] == 0)
+                    continue;
+                encoded[g] = std::make_shared<FlowBuffer::Encoded>();
+                encoded[g]->size_x.assign(m_of[g], 0u), encoded[g]->size_y.assign(m_of[g], 0u);
+                for (int i = 0; i < m_of[g]; ++i) {
+                    encoded[g]->x.emplace_back(new uchar[cap]);
+                    encoded[g]->y.emplace_back(new uchar[cap]);
+                    out_x.push_back(encoded[g]->x[i].get());
+                    out_y.push_back(encoded[g]->y[i].get());
+                }
             }
-            const int jrc = dfx_submit_batch_jpeg(dfx_, in.data(), frames_gray.item_data[0].step, N, step, -bound, bound,
+            declare();
+            const int jrc = dfx_submit_batch_jpeg(dfx_, in.data(), first->step, N, step, -bound, bound,
                                                   95 /* cv::imencode's default quality */, out_x.data(), out_y.data(), cap,
-                                                  encoded->size_x.data(), encoded->size_y.data(), &ticket);
+                                                  pend->size_x.data(), pend->size_y.data(), &ticket);
             if (jrc == DFX_OK) {
-                flows.clear();
                 encoded_on_device = true;
             } else if (jrc != DFX_ERR_UNSUPPORTED) { // UNSUPPORTED: planes that do not compress; encode them on the host
                 throw std::runtime_error(dfx_last_error(dfx_));
             } else {
-                encoded.reset();
+                for (auto &e : encoded)
+                    e.reset();
+                pend->size_x.clear(), pend->size_y.clear();
             }
         }
         if (encoded_on_device) {
         } else if (device_bounding) {
             // encodeFlowMap's convertFlowToImage(-bound, bound) (src/common.cpp:52) happens on the device:
             // two 8-bit planes per flow come back instead of a float field
-            flows.resize(2 * (size_t)M);
-            vector<uint8_t *> out_x(M), out_y(M);
-            for (int i = 0; i < M; ++i) {
-                flows[2 * i].create(sz, CV_8UC1);
-                flows[2 * i + 1].create(sz, CV_8UC1);
-                out_x[i] = flows[2 * i].ptr<uint8_t>();
-                out_y[i] = flows[2 * i + 1].ptr<uint8_t>();
+            vector<uint8_t *> out_x, out_y;
+            size_t out_step = 0;
+            for (size_t g = 0; g < group.size(); ++g) {
+                flows[g].resize(2 * (size_t)m_of[g]);
+                for (int i = 0; i < m_of[g]; ++i) {
+                    flows[g][2 * i].create(sz, CV_8UC1);
+                    flows[g][2 * i + 1].create(sz, CV_8UC1);
+                    out_x.push_back(flows[g][2 * i].ptr<uint8_t>());
+                    out_y.push_back(flows[g][2 * i + 1].ptr<uint8_t>());
+                    out_step = flows[g][2 * i].step;
+                }
             }
-            if (dfx_submit_batch_u8(dfx_, in.data(), frames_gray.item_data[0].step, N, step, -bound, bound,
-                                    out_x.data(), out_y.data(), flows[0].step, &ticket) != DFX_OK)
+            declare();
+            if (dfx_submit_batch_u8(dfx_, in.data(), first->step, N, step, -bound, bound, out_x.data(), out_y.data(),
+                                    out_step, &ticket) != DFX_OK)
                 throw std::runtime_error(dfx_last_error(dfx_));
         } else {
-            vector<float *> out(M);
-            for (int i = 0; i < M; ++i) {
-                flows[i].create(sz, CV_32FC2);
-                out[i] = flows[i].ptr<float>();
+            vector<float *> out;
+            size_t out_step = 0;
+            for (size_t g = 0; g < group.size(); ++g) {
+                flows[g].resize(m_of[g]);
+                for (int i = 0; i < m_of[g]; ++i) {
+                    flows[g][i].create(sz, CV_32FC2);
+                    out.push_back(flows[g][i].ptr<float>());
+                    out_step = flows[g][i].step;
+                }
             }
-            if (dfx_submit_batch(dfx_, in.data(), frames_gray.item_data[0].step, N, step, out.data(), flows[0].step,
-                                 &ticket) != DFX_OK)
+            declare();
+            if (dfx_submit_batch(dfx_, in.data(), first->step, N, step, out.data(), out_step, &ticket) != DFX_OK)
                 throw std::runtime_error(dfx_last_error(dfx_));
         }
         TRACE("calc: FlowBuffer submitted, ticket %llu", (unsigned long long)ticket);
         total_flows += M;
+        pend->ticket = ticket;
+        pend->handle = ticket ? dfx_ : nullptr;
     }
     if (verbose)
         cout << "flows queue push a item" << endl;
     // the collector thread waits for the tail (last download + hand-over) and pushes the flows to the save stage
     // while this thread already submits the next FlowBuffer
-    FlowBuffer result(flows, frames_gray.output_dir, frames_gray.base_start, frames_gray.last_buffer,
-                      device_bounding && M > 0);
-    result.encoded = encoded;
-    enqueue_pending(std::unique_ptr<PendingFlows>(new PendingFlows{std::move(result), ticket, is_final,
-                                                                   ticket ? dfx_ : nullptr}));
+    for (size_t g = 0; g < group.size(); ++g) {
+        FlowBuffer result(std::move(flows[g]), group[g].output_dir, group[g].base_start, group[g].last_buffer,
+                          device_bounding && m_of[g] > 0);
+        result.encoded = encoded[g];
+        pend->flows.push_back(std::move(result));
+    }
+    enqueue_pending(std::move(pend));
     // DF_SYNC_FLOW=1 (A/B measurements): collect every FlowBuffer at once, like the synchronous dfx_calc_batch*
     static const bool sync_flow = std::getenv("DF_SYNC_FLOW") != nullptr;
     if (sync_flow)
@@ -531,15 +625,55 @@ void DenseFlow::calc_optflows(bool verbose) {
     thread collector([this] { collect_flows(); });
     std::exception_ptr err;
     try {
+        // Joining: a FlowBuffer of at most 64 Mpx of frames may take along the FlowBuffers of the same geometry that are
+        // ALREADY queued (nothing waits for a clip that has not been loaded yet), up to 256 Mpx per group.
+        const size_t kJoinEach = 64u << 20, kJoinTotal = 256u << 20;
+        auto frame_px = [](const FlowBuffer &b) {
+            return b.item_data.empty() ? (size_t)0 : b.item_data.size() * (size_t)b.item_data[0].rows * b.item_data[0].cols;
+        };
+        auto same_geometry = [](const FlowBuffer &a, const FlowBuffer &b) {
+            const Mat &x = a.item_data[0], &y = b.item_data[0];
+            return x.size() == y.size() && x.step == y.step && x.type() == y.type() && a.target == b.target;
+        };
+        std::unique_ptr<std::pair<FlowBuffer, bool>> carry; // popped while joining, but it does not fit the group
         while (true) {
             bool is_final = false;
-            FlowBuffer frames_gray = frames_gray_queue.pop(&is_final);
-            flows_final_ = is_final;
-            if (frames_gray.engine_hint.width > 0) { // the loader's early notice: allocate while it reads the first frames
-                prepare_engine(algorithm, frames_gray.engine_hint);
+            vector<FlowBuffer> group;
+            if (carry) {
+                group.push_back(std::move(carry->first));
+                is_final = carry->second;
+                carry.reset();
+            } else {
+                group.push_back(frames_gray_queue.pop(&is_final));
+            }
+            if (group[0].engine_hint.width > 0) { // the loader's early notice: allocate while it reads the first frames
+                flows_final_ = is_final;
+                prepare_engine(algorithm, group[0].engine_hint);
                 continue;
             }
-            calc_optflows_imp(frames_gray, algorithm, step, false, stream);
+            size_t px = frame_px(group[0]);
+            while (join_short_ && !is_final && !group[0].item_data.empty() && px <= kJoinEach && group.size() < 64) {
+                FlowBuffer next({}, path(), 0, false);
+                bool fin = false;
+                if (!frames_gray_queue.try_pop(next, &fin))
+                    break;
+                if (next.engine_hint.width > 0 && !fin) {
+                    if (dfx_ && next.engine_hint == dfx_size_)
+                        continue; // the next video has this group's size: its engine exists
+                    carry.reset(new std::pair<FlowBuffer, bool>(std::move(next), fin));
+                    break;
+                }
+                const size_t npx = frame_px(next);
+                if (!next.item_data.empty() && (!same_geometry(group[0], next) || px + npx > kJoinTotal)) {
+                    carry.reset(new std::pair<FlowBuffer, bool>(std::move(next), fin));
+                    break;
+                }
+                px += npx;
+                group.push_back(std::move(next));
+                is_final = fin;
+            }
+            flows_final_ = is_final;
+            submit_group(group, algorithm, step, false);
             if (is_final)
                 break;
         }

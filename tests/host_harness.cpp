@@ -196,6 +196,44 @@ int hh_queue_close_unblocks() {
     return woke.load() == 2;
 }
 
+// try_pop and the byte budget: a depth-1 queue with a budget of `budget` bytes takes small buffers (each `frame_bytes`) until
+// the budget (or hard_max) is reached, try_pop drains it in order and then reports "nothing queued".  Returns the number of
+// buffers a producer could push without blocking, or -1 on disorder.
+int hh_queue_budget(int frame_bytes, int budget, int hard_max) {
+    FlowBufferQueue q(1);
+    q.set_byte_budget((size_t)budget, (size_t)hard_max);
+    std::atomic<int> pushed(0);
+    thread producer([&] {
+        for (int i = 0; i < 1000; ++i) {
+            vector<Mat> frames(1);
+            frames[0].create(Size(frame_bytes, 1), CV_8UC1);
+            q.push(FlowBuffer(std::move(frames), path(), i, false), false);
+            pushed += 1;
+        }
+    });
+    int last = -1;
+    for (int spins = 0; spins < 200; ++spins) { // wait until the producer is blocked: the count stops growing
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        const int now = pushed.load();
+        if (now == last)
+            break;
+        last = now;
+    }
+    const int accepted = pushed.load();
+    bool ok = true;
+    int expect = 0;
+    FlowBuffer b({}, path(), 0, false);
+    bool fin = false;
+    for (int i = 0; i < accepted; ++i)
+        ok = ok && q.try_pop(b, &fin) && b.base_start == expect++ && !fin;
+    q.close(); // the producer's blocked push returns, later pushes are dropped
+    producer.join();
+    while (q.try_pop(b, &fin)) { // what slipped in between the drain and close()
+    }
+    ok = ok && !q.try_pop(b, &fin);
+    return ok ? accepted : -1;
+}
+
 // parallelFor: sum of i over [0, n) computed on `threads` workers; throws_at >= 0 makes that index throw.
 long hh_parallel_sum(int n, int threads, int throws_at) {
     std::atomic<long> sum(0);

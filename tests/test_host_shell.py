@@ -256,6 +256,11 @@ def test_flow_buffer_queue_orders_blocks_and_closes(harness):
     for n, depth in [(1, 1), (10, 1), (200, 3), (50, 64)]:
         assert harness.hh_queue_roundtrip(n, depth) == n * (n - 1) // 2
     assert harness.hh_queue_close_unblocks() == 1
+    # byte budget (short clips may queue up for the joining flow stage): depth 1, but buffers are accepted while fewer
+    # than `budget` bytes and fewer than `hard_max` buffers are queued; try_pop drains in order without blocking
+    assert harness.hh_queue_budget(1000, 4500, 48) == 5   # the fifth push still sees 4000 < 4500 queued
+    assert harness.hh_queue_budget(1000, 10 ** 6, 7) == 7  # hard_max
+    assert harness.hh_queue_budget(1000, 0, 48) == 1       # no budget: the reference's bound alone
 
 
 def test_parallel_for_covers_every_index_and_propagates_errors(harness):
@@ -329,6 +334,39 @@ def test_cli_device_jpeg_writes_the_same_files_as_the_host_encoders(built, tmp_p
     for other in ("host_jpeg", "all_host"):
         assert outs["gpu_jpeg"].keys() == outs[other].keys()
         assert all(outs["gpu_jpeg"][f] == outs[other][f] for f in outs["gpu_jpeg"]), other
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("st,env", [("jpg", {}), ("jpg", {"DF_HOST_JPEG": "1"}), ("png", {}), ("h5", {}), ("jpg", {"DF_TRACE": "1"})])
+def test_cli_list_of_short_clips_is_joined_without_changing_a_byte(built, tmp_path, st, env):
+    """A list of short clips (BASELINE configs[3] in small): the flow stage joins the clips that are already queued into one
+    library call (dfx_next_segments) — every file must be what the unjoined run (DF_NO_JOIN=1) writes.  Clips of unequal
+    lengths, one with no pair at all, one of another size in the middle (it ends a group), .done records on."""
+    shapes = [(64, 48, 7), (64, 48, 5), (64, 48, 2), (64, 48, 9), (96, 64, 6), (64, 48, 4), (64, 48, 8)]
+    lines = []
+    for i, (w, h, n) in enumerate(shapes):
+        clip = tmp_path / f"clip{i}.y4m"
+        write_y4m(clip, SynthClip(w, h, 40 + i).frames(n))
+        lines.append(str(clip))
+    lst = tmp_path / "list.txt"
+    lst.write_text("\n".join(lines) + "\n")
+    outs = {}
+    for tag, extra in (("joined", {}), ("single", {"DF_NO_JOIN": "1"})):
+        out = tmp_path / tag
+        r = subprocess.run([built, str(lst), "-o=" + str(out), "-a=farn", "-s=2", "-b=20", "-st=" + st],
+                           capture_output=True, text=True, env={**os.environ, **env, **extra})
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = {str(p.relative_to(out)): p.read_bytes() for p in sorted(out.rglob("*")) if p.is_file()}
+        if "DF_TRACE" in env:  # the trace shows how many FlowBuffers went into each library call
+            import re
+
+            sizes = [int(m) for m in re.findall(r"frames of (\d+) FlowBuffer", r.stderr)]
+            assert sizes and (max(sizes) > 1 if tag == "joined" else max(sizes) == 1), sizes
+    assert outs["joined"].keys() == outs["single"].keys() and len(outs["joined"]) > 0
+    if st == "jpg":
+        assert sum(1 for f in outs["joined"] if f.endswith(".jpg")) == 2 * sum(max(n - 2, 0) for _, _, n in shapes)
+    for f in outs["joined"]:
+        assert outs["joined"][f] == outs["single"][f], f
 
 
 def _write_pgm_dir(d, frames):
