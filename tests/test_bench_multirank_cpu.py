@@ -83,6 +83,15 @@ def test_self_launch_weak(world):
     assert out["config"]["pairs_per_step"] == world * 40
 
 
+def test_self_launch_list_of_short_clips_per_rank():
+    """--clips N: every rank owns N clips joined into one FlowBuffer (the videolist of BASELINE configs[3] sharded over the
+    GPUs); pairs never cross a clip boundary, so a rank counts N * (frames - |step|) of them."""
+    out = _self_launched(2, ["--clips", "3", "--step", "2"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["pairs_per_step"] == 2 * 3 * (41 - 2)
+    assert "clips x 3 in one FlowBuffer" in out["config"]["workload"] and "3 clips per GPU" in out["config"]["workload"]
+
+
 def test_self_launch_strong_splits_one_clip():
     out = _self_launched(2, ["--split", "clip", "--step", "-2"])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong"
