@@ -6,7 +6,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 CXXFLAGS ?= -O3 -std=c++17 -Wall -Wextra -fPIC -Iinclude
 CSRC     := $(wildcard denseflow_amd/csrc/*.hip denseflow_amd/csrc/*.cpp)
-CHDR     := $(wildcard denseflow_amd/csrc/*.h) include/dfx.h
+CHDR     := $(wildcard denseflow_amd/csrc/*.h) $(wildcard include/dfx*.h)
 LIB      := denseflow_amd/lib/libdfx.so
 HOSTSRC  := src/common.cpp src/utils.cpp src/image_io.cpp src/h5mini.cpp src/denseflow_gpu.cpp
 HOSTOBJ  := $(patsubst src/%.cpp,build/%.o,$(HOSTSRC))

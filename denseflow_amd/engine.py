@@ -107,8 +107,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     srcs = sorted(
         os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".hip") or f.endswith(".cpp")
     )
+    inc = os.path.join(_ROOT, "include")
     deps = srcs + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")] + [
-        os.path.join(_ROOT, "include", "dfx.h")
+        os.path.join(inc, f) for f in os.listdir(inc) if f.startswith("dfx") and f.endswith(".h")
     ]
     if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(d) for d in deps):
         return _LIB
