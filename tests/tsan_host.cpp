@@ -11,6 +11,31 @@ int main(int argc, char **argv) {
     thread prod([&] { for (int i = 0; i < 500; ++i) q.push(FlowBuffer({}, path(), i, false), i == 499); });
     long sum = 0; while (true) { bool fin = false; FlowBuffer b = q.pop(&fin); sum += b.base_start; if (fin) break; }
     prod.join();
+    // the joining consumer's pattern: a byte budget lets short buffers accumulate, try_pop takes along what is queued
+    {
+        FlowBufferQueue jq(3);
+        jq.set_byte_budget(1 << 20, 48);
+        thread jp([&] {
+            for (int i = 0; i < 400; ++i) {
+                vector<Mat> fr(1);
+                fr[0].create(Size(64, 1 + i % 5), CV_8UC1);
+                jq.push(FlowBuffer(std::move(fr), path(), i, false), i == 399);
+            }
+        });
+        int expect = 0;
+        bool done = false;
+        while (!done) {
+            bool fin = false;
+            FlowBuffer b = jq.pop(&fin);
+            if (b.base_start != expect++) sum = -1000000;
+            FlowBuffer nx({}, path(), 0, false);
+            while (!fin && jq.try_pop(nx, &fin))
+                if (nx.base_start != expect++) sum = -1000000;
+            done = fin;
+        }
+        jp.join();
+        if (expect != 400) sum = -1000000;
+    }
     // parallel opens + reads + jpeg encodes with pooled Mats
     std::atomic<int> bad(0);
     parallelFor(8, 8, [&](int) {
