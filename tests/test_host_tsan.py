@@ -36,5 +36,6 @@ def test_host_shell_pieces_are_race_free_under_tsan(tmp_path):
             f.write(((np.arange(w * h, dtype=np.uint32) * 7 + i) & 0xFF).astype(np.uint8).tobytes())
     r = subprocess.run([exe, str(clip)], capture_output=True, text=True, env={**os.environ, "TSAN_OPTIONS": "halt_on_error=0"})
     assert "bad 0" in r.stdout, r.stdout + r.stderr[-2000:]
+    assert "sum 124750 " in r.stdout, r.stdout  # 0 + ... + 499 through the queue, and the joining pattern kept its order
     assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0
