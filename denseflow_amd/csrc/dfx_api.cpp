@@ -10,6 +10,7 @@
 #include <functional>
 
 #include "dfx_internal.h"
+#include "dfx_plan.h"
 #include "jpeg_kernels.h"
 #include "prepare_kernels.h"
 #include "quantize_kernels.h"
@@ -263,11 +264,6 @@ inline hipError_t copy_rows_async(void *dst, size_t dpitch, const void *src, siz
     return hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, rows, kind, s);
 }
 
-struct BatchPlan {
-    int i0, nb;          // pairs [i0, i0+nb)
-    long long first_new; // first frame id that has to be prepared for this batch
-    int n_new;           // number of such frames
-};
 
 // Shared driver for host- and device-resident frames.
 //   host mode  : frames[i] host pointers (frame_pitch), flows[i] host pointers (out_pitch bytes).
@@ -306,31 +302,14 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         if (total != n_frames)
             return dfx_fail(c, DFX_ERR_INVALID, "dfx_next_segments: the clip lengths do not add up to n_frames");
     }
-    std::vector<int> pair_lo, pair_hi; // the two frames of pair i: lo < hi (which of them is `a` depends on the step's sign)
-    {
-        int off = 0;
-        for (int n : seg) {
-            for (int i = 0; i + astep < n; ++i) {
-                pair_lo.push_back(off + i);
-                pair_hi.push_back(off + i + astep);
-            }
-            off += n;
-        }
-    }
-    const int M = (int)pair_lo.size();
+    const DfxPairs pairs = dfx_build_pairs(seg, step); // dfx_plan.h: pure host logic, CPU-tested
+    const int M = pairs.size();
     if (M == 0)
         return DFX_OK;
     HIPCHK(c, hipSetDevice(c->device));
     AlgoEngine *E = c->engine;
     int B = E->batch();
-    // frames that one batch of B pairs can need: B + |step| inside one clip, |step| more for every clip boundary it spans
-    auto frames_needed = [&](int b) {
-        int need = 0;
-        for (int i0 = 0; i0 < M; i0 += b)
-            need = std::max(need, pair_hi[std::min(i0 + b, M) - 1] - pair_lo[i0] + 1);
-        return need;
-    };
-    int F_need = std::max(frames_needed(B), std::min(B, M) + astep);
+    const int F_need = std::max(dfx_frames_needed(pairs, B), std::min(B, M) + astep);
     int rc = E->ensure_frame_slots(F_need);
     if (rc != DFX_OK)
         return rc;
@@ -383,26 +362,13 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
 
     // Frames [lo of its first pair, hi of its last pair] must be resident for a batch; earlier batches already prepared
     // the ids below their own end.  Frame id f lives in slot f % F; F >= that range, so a batch never evicts what it needs.
-    std::vector<BatchPlan> plan;
-    {
-        long long built = 0;
-        for (int i0 = 0; i0 < M; i0 += B) {
-            BatchPlan p;
-            p.i0 = i0;
-            p.nb = std::min(B, M - i0);
-            const long long need_end = (long long)pair_hi[i0 + p.nb - 1] + 1;
-            p.first_new = std::max<long long>(built, pair_lo[i0]);
-            p.n_new = (int)std::max<long long>(need_end - p.first_new, 0);
-            built = std::max(built, need_end);
-            plan.push_back(p);
-        }
-    }
+    const std::vector<DfxBatchPlan> plan = dfx_plan_batches(pairs, B);
     // batches are numbered across calls (q = seq0 + k): batch q uses staging set / bounce buffer / events q & 1
     const unsigned long long seq0 = c->batch_seq;
     c->batch_seq += plan.size();
     auto par = [&](size_t k) -> int { return (int)((seq0 + k) & 1ull); };
     auto upload = [&](size_t k) -> int { // host frames of batch k -> staging set par(k) (upload stream)
-        const BatchPlan &p = plan[k];
+        const DfxBatchPlan &p = plan[k];
         const size_t rb = c->in_row_bytes(), fb = rb * c->in_h();
         unsigned char *dst = prep ? c->d_src[par(k)] : c->d_u8[par(k)];
         // the staging set was last read by the frame preparation of batch q-2 (compute stream)
@@ -437,7 +403,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     };
     std::vector<JpegBatch> jb(out.jpeg ? plan.size() : 0);
     auto download = [&](size_t k) -> int { // flows of batch k: staging set par(k) -> host (download stream)
-        const BatchPlan &p = plan[k];
+        const DfxBatchPlan &p = plan[k];
         const int q = par(k);
         HIPCHK(c, hipStreamWaitEvent(c->d2h_stream, c->ev_compute[q], 0));
         if (out.jpeg) { // the batch's entropy-coded segments, one block; assemble_jpeg(k) turns them into files later
@@ -496,7 +462,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 std::memcpy((char *)dst + (size_t)y * dpitch, (const char *)src + (size_t)y * row_bytes, row_bytes);
     };
     auto scatter = [&](size_t k) -> int { // bounce mode: results of batch k -> the caller's buffers (host memcpy)
-        const BatchPlan &p = plan[k];
+        const DfxBatchPlan &p = plan[k];
         HIPCHK(c, hipEventSynchronize(c->ev_d2h[par(k)]));
         if (out.jpeg) { // header + byte-stuffed segment + EOI for every plane of the batch
             const unsigned char *hb = c->jpeg.h_stream[par(k)];
@@ -546,7 +512,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         ~Post() { (void)finish(); }
     } post;
     for (size_t k = 0; k < plan.size(); ++k) {
-        const BatchPlan &p = plan[k];
+        const DfxBatchPlan &p = plan[k];
         if (host_mode) {
             // flows of batch k-1 down (download stream, after its compute), frames of batch k+1 up (upload stream,
             // after the frame preparation of batch k-1, which last read that staging set)
@@ -607,8 +573,8 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         // pair i of a clip: a = (step>0 ? i : i-step), b = (step>0 ? i+step : i)   (src/denseflow_gpu.cpp:315-316)
         for (int j = 0; j < p.nb; ++j) {
             const int i = p.i0 + j;
-            c->h_pairs[j].frame_a = (step > 0 ? pair_lo[i] : pair_hi[i]) % F;
-            c->h_pairs[j].frame_b = (step > 0 ? pair_hi[i] : pair_lo[i]) % F;
+            c->h_pairs[j].frame_a = dfx_pair_a(pairs, i, step) % F;
+            c->h_pairs[j].frame_b = dfx_pair_b(pairs, i, step) % F;
         }
         const bool staged = host_mode || out.quantized;
         float *dst = staged ? c->d_flow_out[par(k)] : out.d_flows + (size_t)p.i0 * out.d_flow_stride;
@@ -675,7 +641,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             t->ticket = c->next_ticket++;
             t->parity = par(last);
             dfx_context::Tail *tp = t.get();
-            const BatchPlan lp = plan[last];
+            const DfxBatchPlan lp = plan[last];
             hipEvent_t ev = c->ev_d2h[par(last)];
             const unsigned char *hb = bounce ? c->h_out[par(last)] : nullptr;
             const int W = c->W, H = c->H, dev = c->device;
