@@ -1,0 +1,213 @@
+"""The host shell's own logic on the CPU: tools/denseflow.cpp + src/*.cpp linked against tests/stub_dfx.cpp — a FAKE of the
+C ABI (include/dfx.h) that is test infrastructure only: its "flows" are a made-up function of the two frames.  What is tested
+is everything around the library call: the loader / flow / collector / save threads, FlowBuffer boundaries, the joining of
+short clips (dfx_next_segments), device pipelines (-g), frame-to-pair selection and output indices, naming, .done records,
+the jpg / png / h5 writers, the resize hand-off.  The GPU suite runs the same CLI against the real library and the oracle
+(tests/test_host_shell.py); the real CLI must refuse to run without a device."""
+import ctypes as C
+import io
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from denseflow_amd.synth import SynthClip
+from tests.test_host_shell import BIN, ROOT, _write_pgm_dir, built, harness, write_y4m  # noqa: F401
+
+STUB = os.path.join(ROOT, "tests", "_build", "denseflow_stub")
+
+
+@pytest.fixture(scope="module")
+def stub(built):
+    os.makedirs(os.path.dirname(STUB), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", STUB,
+           os.path.join(ROOT, "tools", "denseflow.cpp"), os.path.join(ROOT, "tests", "stub_dfx.cpp"),
+           os.path.join(ROOT, "build", "libzzdenseflow.a"), "-lpthread", "-lz"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return STUB
+
+
+def _run(exe, args, env=None):
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, env={**os.environ, **(env or {})})
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r
+
+
+def _files(root):
+    return {str(p.relative_to(root)): p.read_bytes() for p in sorted(root.rglob("*")) if p.is_file()}
+
+
+def _fake_flow(a, b):
+    """tests/stub_dfx.cpp: fake_flow, in float32 like the stub."""
+    a = a.astype(np.float32)
+    b = b.astype(np.float32)
+    h, w = a.shape
+    x = np.arange(w, dtype=np.float32)[None, :]
+    y = (np.arange(h) % 7).astype(np.float32)[:, None]
+    u = (b - a) * np.float32(0.125) + np.float32(0.01) * x - np.float32(0.3)
+    v = (np.roll(a, -1, axis=1) - b) * np.float32(0.0625) + np.float32(0.02) * y
+    return np.stack([u, v], -1).astype(np.float32)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU box: the real CLI works here")
+def test_the_real_cli_refuses_to_run_without_a_device(built, tmp_path):
+    clip = tmp_path / "c.y4m"
+    write_y4m(clip, SynthClip(64, 48, 1).frames(3))
+    r = subprocess.run([built, str(clip), "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no HIP device available" in r.stdout + r.stderr
+    assert not any((tmp_path / "o").rglob("*.jpg"))
+
+
+@pytest.mark.parametrize("step", [1, 2, -1, -3])
+def test_every_file_is_the_right_pair_under_the_right_name(stub, harness, oracle, tmp_path, step):
+    """Frame-to-pair selection, bounding and naming through the whole pipeline: file flow_{x,y}[_pS|_mS]_%05d.jpg number i
+    must hold the (made-up) flow of the reference's pair i — (i, i + s) for s > 0, (i - s, i) otherwise
+    (/root/reference/src/denseflow_gpu.cpp:307-316), bounded by convertFlowToImage and encoded at quality 95 — across several
+    FlowBuffers (DF_BATCH_MAXSIZE=4: |step| frames are carried over, reference :204-207)."""
+    w, h, n = 64, 48, 11
+    frames = SynthClip(w, h, 3).frames(n)
+    clip = tmp_path / "clip.y4m"
+    write_y4m(clip, frames)
+    _run(stub, [clip, "-o=" + str(tmp_path / "out"), "-a=tvl1", "-s=%d" % step, "-b=20"], {"DF_BATCH_MAXSIZE": "4"})
+    got = _files(tmp_path / "out" / "clip")
+    m = n - abs(step)
+    tag = "" if step == 1 else ("_p%d" % step if step > 0 else "_m%d" % -step)
+    base = 0 if step > 0 else -step  # writeFlowImages (reference src/common.cpp:73-100): names count from the LATER frame
+    assert sorted(got) == sorted(f"flow_{c}{tag}_{i + base:05d}.jpg" for c in "xy" for i in range(m))
+    harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    buf = np.zeros(1 << 20, np.uint8)
+    for i in range(m):
+        a, b = (frames[i], frames[i + step]) if step > 0 else (frames[i - step], frames[i])
+        for c, plane in zip("xy", oracle.flow_to_u8(_fake_flow(a, b), -20.0, 20.0)):
+            plane = np.ascontiguousarray(plane)
+            k = harness.hh_encode_jpeg(plane.ctypes.data, w, h, 95, buf.ctypes.data, buf.size)
+            assert got[f"flow_{c}{tag}_{i + base:05d}.jpg"] == buf[:k].tobytes(), (c, i)
+
+
+@pytest.mark.parametrize("st,env", [("jpg", {}), ("jpg", {"DF_HOST_JPEG": "1"}), ("jpg", {"STUB_JPEG_UNSUPPORTED": "1"}),
+                                    ("jpg", {"DF_HOST_BOUND": "1"}), ("png", {}), ("h5", {})])
+def test_a_list_of_short_clips_is_joined_without_changing_a_byte(stub, tmp_path, st, env):
+    """The flow stage joins the queued FlowBuffers of one geometry into one library call; DF_NO_JOIN=1 does not.  Clips of
+    unequal lengths, one without a pair, one of another size in the middle; every save type and every bounding / encoding
+    place (device JPEG, host JPEG, the UNSUPPORTED fallback, all-host)."""
+    import re
+
+    shapes = [(64, 48, 7), (64, 48, 5), (64, 48, 2), (64, 48, 9), (96, 64, 6), (64, 48, 4), (64, 48, 8)]
+    lines = []
+    for i, (w, h, n) in enumerate(shapes):
+        write_y4m(tmp_path / f"clip{i}.y4m", SynthClip(w, h, 40 + i).frames(n))
+        lines.append(str(tmp_path / f"clip{i}.y4m"))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    outs, groups = {}, {}
+    for tag, extra in (("joined", {}), ("single", {"DF_NO_JOIN": "1"})):
+        r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / tag), "-a=farn", "-s=2", "-b=20", "-st=" + st],
+                 {**env, **extra, "DF_TRACE": "1"})
+        outs[tag] = _files(tmp_path / tag)
+        groups[tag] = [int(g) for g in re.findall(r"frames of (\d+) FlowBuffer", r.stderr)]
+    assert max(groups["single"]) == 1
+    assert outs["joined"].keys() == outs["single"].keys() and outs["joined"]
+    for f in outs["joined"]:
+        assert outs["joined"][f] == outs["single"][f], f
+    if st == "jpg":
+        assert sum(f.endswith(".jpg") for f in outs["joined"]) == 2 * sum(max(n - 2, 0) for _, _, n in shapes)
+
+
+def test_joining_really_happens_when_clips_are_waiting(stub, tmp_path):
+    """With the loader far ahead (tiny clips, a flow stage that has to create its engine first) at least one library call must
+    carry several FlowBuffers — otherwise the byte-for-byte test above would compare two unjoined runs."""
+    import re
+
+    lines = []
+    for i in range(24):
+        write_y4m(tmp_path / f"c{i}.y4m", SynthClip(32, 24, i).frames(6))
+        lines.append(str(tmp_path / f"c{i}.y4m"))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    best = 0
+    for _ in range(3):  # scheduling decides how many are queued at a given moment: any run that joins proves the path
+        r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1", "-f"], {"DF_TRACE": "1"})
+        best = max([best] + [int(g) for g in re.findall(r"frames of (\d+) FlowBuffer", r.stderr)])
+        if best > 1:
+            break
+    assert best > 1
+
+
+@pytest.mark.parametrize("source", ["video", "frames"])
+def test_flowbuffer_boundaries_and_device_pipelines_do_not_change_the_files(stub, tmp_path, source):
+    """FlowBuffers are a pipelining unit and -g a sharding of independent work: short buffers, and one clip split over three
+    device pipelines (Level 2: every pipeline loads its |step| overlap frames itself), must write the single-buffer,
+    single-pipeline files."""
+    w, h, n, step = 64, 48, 23, 2
+    frames = SynthClip(w, h, 9).frames(n)
+    if source == "video":
+        src = tmp_path / "clip.y4m"
+        write_y4m(src, frames)
+        extra = []
+    else:
+        src = tmp_path / "clip"
+        _write_pgm_dir(src, frames)
+        extra = ["--if"]
+    base = [src, "-a=farn", "-s=%d" % step, "-b=20"] + extra
+    _run(stub, base + ["-o=" + str(tmp_path / "one")])
+    _run(stub, base + ["-o=" + str(tmp_path / "short")], {"DF_BATCH_MAXSIZE": "5"})
+    _run(stub, base + ["-o=" + str(tmp_path / "split"), "-g=3"], {"STUB_DEVICES": "3", "DF_BATCH_MAXSIZE": "4"})
+    one = _files(tmp_path / "one")
+    assert len([f for f in one if f.endswith(".jpg")]) == 2 * (n - step)
+    assert _files(tmp_path / "short") == one
+    assert _files(tmp_path / "split") == one
+
+
+def test_a_list_sharded_over_device_pipelines_and_done_records(stub, tmp_path):
+    """Level 1: the videos of a list are dealt to the device pipelines; the files and the .done records are those of one
+    pipeline, and a second run skips every video that is marked done (no -f)."""
+    lines = []
+    for i in range(5):
+        write_y4m(tmp_path / f"v{i}.y4m", SynthClip(48, 32, 60 + i).frames(4 + i))
+        lines.append(str(tmp_path / f"v{i}.y4m"))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "g1"), "-a=farn", "-s=1"])
+    _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "g2"), "-a=farn", "-s=1", "-g=2"], {"STUB_DEVICES": "2"})
+    one, two = _files(tmp_path / "g1"), _files(tmp_path / "g2")
+    assert one == two
+    assert sum(f.endswith(".jpg") for f in one) == 2 * sum(3 + i for i in range(5))
+    assert sorted(f for f in one if ".done" in f) == [f".done/v{i}" for i in range(5)]
+    before = {f: os.stat(tmp_path / "g1" / f).st_mtime_ns for f in one}
+    r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "g1"), "-a=farn", "-s=1"])
+    assert "processed" not in r.stdout  # every video is marked done: nothing is read, computed or written again
+    assert {f: os.stat(tmp_path / "g1" / f).st_mtime_ns for f in one} == before
+    r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "g1"), "-a=farn", "-s=1", "-f"])  # -f: regardless
+    assert "5 videos" in r.stdout and _files(tmp_path / "g1") == one
+
+
+def test_resize_on_the_flow_stage_equals_resize_on_the_loader(stub, tmp_path):
+    """-nw / -nh: by default the frames go to the library at their source size (dfx_set_source_format; the stub resizes with
+    the host's resizeLinear), DF_HOST_RESIZE=1 resizes on the loader thread: the same frames reach the pair function."""
+    clip = tmp_path / "clip.y4m"
+    write_y4m(clip, SynthClip(80, 60, 5).frames(6))
+    args = [clip, "-a=farn", "-s=1", "-nw=48", "-nh=32"]
+    _run(stub, args + ["-o=" + str(tmp_path / "dev")])
+    _run(stub, args + ["-o=" + str(tmp_path / "host")], {"DF_HOST_RESIZE": "1"})
+    dev = _files(tmp_path / "dev")
+    assert dev == _files(tmp_path / "host") and len(dev) >= 10
+    from PIL import Image
+
+    assert Image.open(io.BytesIO(next(v for k, v in dev.items() if k.endswith(".jpg")))).size == (48, 32)
+
+
+def test_the_stub_is_test_infrastructure_only():
+    """Nothing the product builds or loads may know the fake: no CPU path hides behind the C ABI."""
+    hits = []
+    for top in ("denseflow_amd", "src", "tools", "include", "oracle"):
+        for d, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".so", ".o", ".a", ".pyc", ".npz")):
+                    continue
+                with open(os.path.join(d, f), errors="ignore") as fh:
+                    if "stub_dfx" in fh.read():
+                        hits.append(os.path.join(d, f))
+    for f in ("Makefile", "bench.py", "__graft_entry__.py"):
+        with open(os.path.join(ROOT, f)) as fh:
+            if "stub_dfx" in fh.read():
+                hits.append(f)
+    assert hits == []

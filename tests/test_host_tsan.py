@@ -39,3 +39,37 @@ def test_host_shell_pieces_are_race_free_under_tsan(tmp_path):
     assert "sum 124750 " in r.stdout, r.stdout  # 0 + ... + 499 through the queue, and the joining pattern kept its order
     assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
     assert r.returncode == 0
+
+
+def test_whole_pipeline_is_race_free_under_tsan(tmp_path):
+    """The complete shell — loader, flow stage (joining queued clips), collector, save stage, two device pipelines — under
+    ThreadSanitizer on the CPU, against the fake C ABI of tests/stub_dfx.cpp (test infrastructure; see
+    tests/test_host_pipeline_stub.py)."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "denseflow_stub_tsan")
+    srcs = [os.path.join(ROOT, "tools", "denseflow.cpp"), os.path.join(ROOT, "tests", "stub_dfx.cpp")] + [
+        os.path.join(ROOT, "src", f) for f in ("common.cpp", "image_io.cpp", "utils.cpp", "h5mini.cpp", "denseflow_gpu.cpp")]
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include")] + srcs +
+                       ["-lpthread", "-lz", "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and ("tsan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("ThreadSanitizer build not available here: " + r.stderr[-300:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = []
+    for i in range(12):
+        clip = tmp_path / f"c{i}.y4m"
+        w, h, n = (48, 32, 5 + i % 4) if i != 7 else (64, 40, 6)
+        with open(clip, "wb") as f:
+            f.write(f"YUV4MPEG2 W{w} H{h} F30:1 Ip A1:1 Cmono\n".encode())
+            for k in range(n):
+                f.write(b"FRAME\n")
+                f.write(((np.arange(w * h, dtype=np.uint32) * (3 + i) + 11 * k) & 0xFF).astype(np.uint8).tobytes())
+        lines.append(str(clip))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    for extra_args, env in (([], {}), (["-g=2"], {"STUB_DEVICES": "2"}), (["-st=png"], {"DF_BATCH_MAXSIZE": "3"}),
+                            (["-st=h5"], {}), ([], {"DF_HOST_JPEG": "1", "DF_ENCODE_THREADS": "4"})):
+        out = tmp_path / ("o" + "".join(extra_args).replace("=", "").replace("-", "") + "".join(env))
+        r = subprocess.run([exe, str(tmp_path / "list.txt"), "-o=" + str(out), "-a=farn", "-s=1"] + extra_args,
+                           capture_output=True, text=True, env={**os.environ, "TSAN_OPTIONS": "halt_on_error=0", **env})
+        assert "WARNING: ThreadSanitizer" not in r.stderr, (extra_args, env, r.stderr[-4000:])
+        assert r.returncode == 0 and "12 videos" in r.stdout, r.stdout + r.stderr[-2000:]
