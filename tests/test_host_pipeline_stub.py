@@ -195,6 +195,40 @@ def test_resize_on_the_flow_stage_equals_resize_on_the_loader(stub, tmp_path):
     assert Image.open(io.BytesIO(next(v for k, v in dev.items() if k.endswith(".jpg")))).size == (48, 32)
 
 
+def test_class_folder_layout_and_frame_extraction(stub, tmp_path):
+    """--cf: outputDir/class/video/flow.jpg and .done/class/video (reference tools/denseflow.cpp:54-82, src/denseflow_gpu.cpp:
+    456-470); -s=0: the frames themselves as img_%05d.jpg (reference :82-144 — gray here, the notice says so)."""
+    lines = []
+    for i, cls in enumerate(["catA", "catB", "catA"]):
+        (tmp_path / cls).mkdir(exist_ok=True)
+        write_y4m(tmp_path / cls / f"v{i}.y4m", SynthClip(48, 32, 60 + i).frames(4))
+        lines.append(str(tmp_path / cls / f"v{i}.y4m"))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1", "--cf"])
+    assert all(f'done video "{c}/v{i}"' in r.stdout for i, c in enumerate(["catA", "catB", "catA"]))
+    got = sorted(_files(tmp_path / "o"))
+    assert got == sorted([f".done/{c}/v{i}" for i, c in enumerate(["catA", "catB", "catA"])] +
+                         [f"{c}/v{i}/flow_{k}_{j:05d}.jpg" for i, c in enumerate(["catA", "catB", "catA"]) for k in "xy"
+                          for j in range(3)])
+    r = _run(stub, [tmp_path / "catA" / "v0.y4m", "-o=" + str(tmp_path / "f"), "-s=0"])
+    assert "GRAY frames" in r.stdout
+    assert sorted(_files(tmp_path / "f")) == [f"v0/img_{j:05d}.jpg" for j in range(4)]
+
+
+def test_an_unreadable_video_ends_the_run_with_the_references_message(stub, tmp_path):
+    """The reference throws "cannot open video_path stream:<path>" on its loader thread (src/denseflow_gpu.cpp:226-228), which
+    ends the process.  Here: the same message, a non-zero exit status, no hang of the other stages, and no .done record for
+    the video that could not be read."""
+    write_y4m(tmp_path / "good.y4m", SynthClip(48, 32, 1).frames(4))
+    (tmp_path / "bad.y4m").write_bytes(b"not a video")
+    (tmp_path / "list.txt").write_text(f"{tmp_path / 'good.y4m'}\n{tmp_path / 'bad.y4m'}\n{tmp_path / 'good.y4m'}\n")
+    r = subprocess.run([stub, str(tmp_path / "list.txt"), "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0
+    assert "cannot open video_path stream:" + str(tmp_path / "bad.y4m") in r.stdout + r.stderr
+    assert not (tmp_path / "o" / ".done" / "bad").exists()
+
+
 def test_the_stub_is_test_infrastructure_only():
     """Nothing the product builds or loads may know the fake: no CPU path hides behind the C ABI."""
     hits = []
