@@ -189,6 +189,27 @@ int dfx_submit_batch_jpeg(dfx_handle h, const uint8_t *const *frames, size_t fra
         h->next_segments.clear();
         return fail(h, DFX_ERR_UNSUPPORTED, "stub: JPEG: the batch does not compress below 4 bits per pixel");
     }
+    if (std::getenv("STUB_FAST")) { // host-stage timing (scripts/host_stage_rate.py): no work at all here, one constant file
+        std::vector<int> seg;
+        seg.swap(h->next_segments);
+        if (seg.empty())
+            seg.push_back(n_frames);
+        const int m = dfx_build_pairs(seg, step).size();
+        static const vector<uchar> file = [&] {
+            Mat flat(Size(h->W, h->H), CV_8UC1);
+            std::memset(flat.data(), 128, flat.total());
+            vector<uchar> f;
+            imencodeJpeg(flat, f, quality);
+            return f;
+        }();
+        for (int i = 0; i < m; ++i) {
+            std::memcpy(jpg_x[i], file.data(), file.size());
+            std::memcpy(jpg_y[i], file.data(), file.size());
+            size_x[i] = size_y[i] = (uint32_t)file.size();
+        }
+        *ticket = m ? h->next_ticket++ : 0;
+        return DFX_OK;
+    }
     Prepared p;
     const int rc = prepare(h, frames, frame_pitch, n_frames, step, p);
     if (rc != DFX_OK)
