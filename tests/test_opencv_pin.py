@@ -40,3 +40,58 @@ def test_hip_path_reproduces_opencv_cuda(dfx, algo):
         with dfx.FlowEngine(w, h, algo) as eng:
             out = eng.calc(f0, f1)
         assert np.max(np.abs(out - flow)) <= TOL, (algo, name)
+
+
+def _imencode_golden():
+    p = os.path.join(GOLDEN, "opencv_imencode.npz")
+    if not os.path.exists(p):
+        pytest.skip(f"{p} absent: run scripts/pin_imencode_against_opencv.py where any cv2 exists (the encoders are pinned "
+                    "to libjpeg-turbo / libpng directly until then: tests/test_jpeg_libjpeg_pin.py, test_png_libpng_pin.py)")
+    return np.load(p)
+
+
+def test_encoders_reproduce_cv2_imencode():
+    """cv2.imencode's own bytes for the planes / images of the committed goldens (default parameters, as the reference calls
+    it): the host encoders must write them.  (libpng / zlib versions differ between OpenCV builds; a PNG mismatch with
+    identical decoded pixels points there, not at the filter / strategy settings.)"""
+    import ctypes as C
+    import subprocess
+
+    from tests.test_host_shell import ROOT
+
+    g = _imencode_golden()
+    r = subprocess.run(["make", "-C", ROOT, "host"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    so = os.path.join(ROOT, "tests", "_build", "libhost_harness_pin.so")
+    os.makedirs(os.path.dirname(so), exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"), "-o", so,
+           os.path.join(ROOT, "tests", "host_harness.cpp"), os.path.join(ROOT, "build", "libzzdenseflow.a"),
+           "-L" + os.path.join(ROOT, "denseflow_amd", "lib"), "-ldfx", "-lpthread", "-lz",
+           "-Wl,-rpath," + os.path.join(ROOT, "denseflow_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"]
+    assert subprocess.run(cmd, capture_output=True, text=True).returncode == 0
+    H = C.CDLL(so)
+    H.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    H.hh_encode_png.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    jg = np.load(os.path.join(GOLDEN, "jpeg_golden.npz"))
+    pg = np.load(os.path.join(GOLDEN, "png_golden.npz"))
+    buf = np.zeros(8 << 20, np.uint8)
+    for k in g.files:
+        if k.startswith("jpg_"):
+            plane = np.ascontiguousarray(jg[k[4:] + "_plane"])
+            n = H.hh_encode_jpeg(plane.ctypes.data, plane.shape[1], plane.shape[0], 95, buf.ctypes.data, buf.size)
+            assert buf[:n].tobytes() == g[k].tobytes(), k
+        elif k.startswith("png_"):
+            img = np.ascontiguousarray(pg[k[4:] + "_image"])
+            n = H.hh_encode_png(img.ctypes.data, img.shape[1], img.shape[0], 1 if img.ndim == 2 else 3, buf.ctypes.data, buf.size)
+            assert buf[:n].tobytes() == g[k].tobytes(), k
+
+
+@pytest.mark.gpu
+def test_device_jpeg_reproduces_cv2_imencode(dfx):
+    g = _imencode_golden()
+    jg = np.load(os.path.join(GOLDEN, "jpeg_golden.npz"))
+    for k in g.files:
+        if k.startswith("jpg_"):
+            plane = jg[k[4:] + "_plane"]
+            with dfx.FlowEngine(plane.shape[1], plane.shape[0], "farn") as eng:
+                assert eng.encode_jpeg([plane], 95)[0] == g[k].tobytes(), k
