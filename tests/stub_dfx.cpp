@@ -5,7 +5,13 @@
 // two frames (below), NOT optical flow; nothing outside tests/ builds or loads this file, and the real CLI
 // (build/denseflow) fails with "no HIP device available" on such a machine (tests/test_host_pipeline_stub.py checks both).
 // Only what the shell calls is implemented.
+//
+// STUB_ORACLE=<path to oracle/liboracle.so>: the pair function is the parity ORACLE's (orc_tvl1_calc / orc_farneback_calc /
+// orc_brox_calc with the reference's default parameters) instead of the made-up one — BASELINE.json's configs[0] / SURVEY.md
+// section 8d "Config 1": the CLI on a CPU, plumbing only (file names, bounding, encoding, "oracle == backend").  Still test
+// infrastructure: the oracle is reachable from tests/ only.
 #include <cstdio>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -17,8 +23,13 @@
 #include "../include/dfx.h"
 #include "../include/image_io.h"
 
+typedef int (*orc_calc_fn)(const uint8_t *, size_t, const uint8_t *, size_t, int, int, const void *, float *, void *);
+typedef int (*orc_calc2_fn)(const uint8_t *, size_t, const uint8_t *, size_t, int, int, const void *, float *);
+
 struct dfx_context {
     int W = 0, H = 0, src_w = 0, src_h = 0;
+    int algo = 0;
+    void *oracle = nullptr; // dlopen handle of liboracle.so (STUB_ORACLE), or NULL: the made-up pair function
     std::vector<int> next_segments;
     std::string err;
     unsigned long long next_ticket = 1;
@@ -33,6 +44,22 @@ int fail(dfx_context *c, int code, const char *msg) {
 
 // the fake "flow" of a pair: depends on both frames, on which of them is `a`, and on the position
 void fake_flow(const dfx_context *c, const uint8_t *a, const uint8_t *b, float *uv, size_t pitch_floats) {
+    if (c->oracle) { // configs[0]: the parity oracle as the "backend" of a CPU plumbing run
+        std::vector<float> dense((size_t)c->W * c->H * 2);
+        int rc = -1;
+        if (c->algo == DFX_ALGO_TVL1) {
+            orc_calc_fn f = (orc_calc_fn)dlsym(c->oracle, "orc_tvl1_calc");
+            rc = f ? f(a, (size_t)c->W, b, (size_t)c->W, c->W, c->H, nullptr, dense.data(), nullptr) : -1;
+        } else {
+            orc_calc2_fn f = (orc_calc2_fn)dlsym(c->oracle, c->algo == DFX_ALGO_FARN ? "orc_farneback_calc" : "orc_brox_calc");
+            rc = f ? f(a, (size_t)c->W, b, (size_t)c->W, c->W, c->H, nullptr, dense.data()) : -1;
+        }
+        if (rc != 0)
+            std::abort();
+        for (int y = 0; y < c->H; ++y)
+            std::memcpy(uv + (size_t)y * pitch_floats, dense.data() + (size_t)y * c->W * 2, sizeof(float) * 2 * c->W);
+        return;
+    }
     for (int y = 0; y < c->H; ++y)
         for (int x = 0; x < c->W; ++x) {
             const int xa = (x + 1) % c->W;
@@ -109,11 +136,18 @@ const char *dfx_algo_error_message(int status, const char *name, char *buf, size
     return buf;
 }
 
-int dfx_create(dfx_handle *out, int device, dfx_algo, int width, int height, const dfx_params *) {
+int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height, const dfx_params *) {
     if (device < 0 || device >= dfx_device_count())
         return DFX_ERR_INVALID;
     dfx_context *c = new dfx_context();
-    c->W = width, c->H = height;
+    c->W = width, c->H = height, c->algo = (int)algo;
+    if (const char *so = std::getenv("STUB_ORACLE")) {
+        c->oracle = dlopen(so, RTLD_NOW | RTLD_LOCAL);
+        if (!c->oracle) {
+            delete c;
+            return DFX_ERR_INVALID;
+        }
+    }
     *out = c;
     return DFX_OK;
 }

@@ -23,7 +23,7 @@ def stub(built):
     os.makedirs(os.path.dirname(STUB), exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-o", STUB,
            os.path.join(ROOT, "tools", "denseflow.cpp"), os.path.join(ROOT, "tests", "stub_dfx.cpp"),
-           os.path.join(ROOT, "build", "libzzdenseflow.a"), "-lpthread", "-lz"]
+           os.path.join(ROOT, "build", "libzzdenseflow.a"), "-lpthread", "-lz", "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return STUB
@@ -58,6 +58,29 @@ def test_the_real_cli_refuses_to_run_without_a_device(built, tmp_path):
     r = subprocess.run([built, str(clip), "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1"], capture_output=True, text=True)
     assert r.returncode != 0 and "no HIP device available" in r.stdout + r.stderr
     assert not any((tmp_path / "o").rglob("*.jpg"))
+
+
+@pytest.mark.parametrize("algo", ["tvl1", "farn"])
+def test_baseline_config_1_the_cli_on_a_cpu_with_the_oracle_as_its_backend(stub, harness, oracle, tmp_path, algo):
+    """BASELINE.json configs[0] / SURVEY.md section 8d Config 1: a single 224x224 synthetic pair (seed 1), -s=1 -b=20, no GPU —
+    plumbing only: the CLI, the file names flow_x_00000.jpg / flow_y_00000.jpg, and "oracle == backend".  The backend here is
+    tests/stub_dfx.cpp handing the pair to the parity oracle (STUB_ORACLE); the files must be the pinned encoder's JPEGs of
+    the oracle's flow bounded by the reference's own convertFlowToImage."""
+    frames = SynthClip(224, 224, 1).frames(2)
+    clip = tmp_path / "pair.y4m"
+    write_y4m(clip, frames)
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    _run(stub, [clip, "-o=" + str(tmp_path / "out"), "-a=" + algo, "-s=1", "-b=20"], {"STUB_ORACLE": so, "OMP_NUM_THREADS": "8"})
+    got = _files(tmp_path / "out" / "pair")
+    assert sorted(got) == ["flow_x_00000.jpg", "flow_y_00000.jpg"]
+    flow = (oracle.tvl1_calc if algo == "tvl1" else oracle.farneback_calc)(frames[0], frames[1])
+    planes = oracle.ref_flow_to_u8(flow, -20.0, 20.0) if oracle.ref_quant_available() else oracle.flow_to_u8(flow, -20.0, 20.0)
+    harness.hh_encode_jpeg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    buf = np.zeros(1 << 20, np.uint8)
+    for c, plane in zip("xy", planes):
+        plane = np.ascontiguousarray(plane)
+        k = harness.hh_encode_jpeg(plane.ctypes.data, 224, 224, 95, buf.ctypes.data, buf.size)
+        assert got[f"flow_{c}_00000.jpg"] == buf[:k].tobytes(), c
 
 
 @pytest.mark.parametrize("step", [1, 2, -1, -3])

@@ -51,7 +51,7 @@ def test_whole_pipeline_is_race_free_under_tsan(tmp_path):
     srcs = [os.path.join(ROOT, "tools", "denseflow.cpp"), os.path.join(ROOT, "tests", "stub_dfx.cpp")] + [
         os.path.join(ROOT, "src", f) for f in ("common.cpp", "image_io.cpp", "utils.cpp", "h5mini.cpp", "denseflow_gpu.cpp")]
     r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include")] + srcs +
-                       ["-lpthread", "-lz", "-o", exe], capture_output=True, text=True)
+                       ["-lpthread", "-lz", "-ldl", "-o", exe], capture_output=True, text=True)
     if r.returncode != 0 and ("tsan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
         pytest.skip("ThreadSanitizer build not available here: " + r.stderr[-300:])
     assert r.returncode == 0, r.stderr[-3000:]
