@@ -14,7 +14,9 @@
 #include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -76,6 +78,8 @@ struct Prepared {
     DfxPairs pairs;
 };
 int prepare(dfx_context *c, const uint8_t *const *frames, size_t pitch, int n_frames, int step, Prepared &out) {
+    if (const char *ms = std::getenv("STUB_DELAY_MS")) // a slow "device": lets the loader run ahead (joining tests)
+        std::this_thread::sleep_for(std::chrono::milliseconds(std::atoi(ms)));
     std::vector<int> seg;
     seg.swap(c->next_segments);
     if (n_frames < 0 || step == 0)

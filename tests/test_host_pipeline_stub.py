@@ -126,10 +126,10 @@ def test_a_list_of_short_clips_is_joined_without_changing_a_byte(stub, tmp_path,
     outs, groups = {}, {}
     for tag, extra in (("joined", {}), ("single", {"DF_NO_JOIN": "1"})):
         r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / tag), "-a=farn", "-s=2", "-b=20", "-st=" + st],
-                 {**env, **extra, "DF_TRACE": "1"})
+                 {**env, **extra, "DF_TRACE": "1", "STUB_DELAY_MS": "15"})  # a slow "device": the loader runs ahead
         outs[tag] = _files(tmp_path / tag)
         groups[tag] = [int(g) for g in re.findall(r"frames of (\d+) FlowBuffer", r.stderr)]
-    assert max(groups["single"]) == 1
+    assert max(groups["single"]) == 1 and max(groups["joined"]) > 1, groups
     assert outs["joined"].keys() == outs["single"].keys() and outs["joined"]
     for f in outs["joined"]:
         assert outs["joined"][f] == outs["single"][f], f
@@ -138,8 +138,8 @@ def test_a_list_of_short_clips_is_joined_without_changing_a_byte(stub, tmp_path,
 
 
 def test_joining_really_happens_when_clips_are_waiting(stub, tmp_path):
-    """With the loader far ahead (tiny clips, a flow stage that has to create its engine first) at least one library call must
-    carry several FlowBuffers — otherwise the byte-for-byte test above would compare two unjoined runs."""
+    """With the loader ahead of the flow stage at least one library call must carry several FlowBuffers — otherwise the
+    byte-for-byte test above would compare two unjoined runs — and every FlowBuffer is in exactly one call."""
     import re
 
     lines = []
@@ -147,13 +147,11 @@ def test_joining_really_happens_when_clips_are_waiting(stub, tmp_path):
         write_y4m(tmp_path / f"c{i}.y4m", SynthClip(32, 24, i).frames(6))
         lines.append(str(tmp_path / f"c{i}.y4m"))
     (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
-    best = 0
-    for _ in range(3):  # scheduling decides how many are queued at a given moment: any run that joins proves the path
-        r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1", "-f"], {"DF_TRACE": "1"})
-        best = max([best] + [int(g) for g in re.findall(r"frames of (\d+) FlowBuffer", r.stderr)])
-        if best > 1:
-            break
-    assert best > 1
+    # a "device" that takes 30 ms per call: while the first call runs the loader queues the other clips, so the next
+    # call must take several of them along
+    r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1"], {"DF_TRACE": "1", "STUB_DELAY_MS": "30"})
+    sizes = [int(g) for g in re.findall(r"frames of (\d+) FlowBuffer", r.stderr)]
+    assert max(sizes) > 1 and sum(sizes) == 24, sizes
 
 
 @pytest.mark.parametrize("source", ["video", "frames"])
