@@ -250,6 +250,37 @@ def test_an_unreadable_video_ends_the_run_with_the_references_message(stub, tmp_
     assert not (tmp_path / "o" / ".done" / "bad").exists()
 
 
+def test_degenerate_inputs_end_cleanly(stub, tmp_path):
+    """Nothing to do must not hang a stage: an empty list, a header-only clip, a one-frame clip, a step longer than every clip
+    of a list (the .done records still fire: an empty FlowBuffer travels the pipeline, reference :358), a truncated last
+    frame (dropped), more device pipelines than pairs, `-a=nv` (the reference's message)."""
+    def run(args, env=None):
+        return subprocess.run([stub] + [str(a) for a in args], capture_output=True, text=True, timeout=60,
+                              env={**os.environ, **(env or {})})
+
+    (tmp_path / "empty.txt").write_text("")
+    assert run([tmp_path / "empty.txt", "-o=" + str(tmp_path / "o1"), "-s=1"]).returncode == 0
+    (tmp_path / "h.y4m").write_bytes(b"YUV4MPEG2 W64 H48 F30:1 Ip A1:1 Cmono\n")
+    r = run([tmp_path / "h.y4m", "-o=" + str(tmp_path / "o2"), "-s=1", "-a=farn"])
+    assert r.returncode == 0 and "(0 frames, 0 farn flows)" in r.stdout
+    write_y4m(tmp_path / "one.y4m", SynthClip(64, 48, 1).frames(1))
+    write_y4m(tmp_path / "three.y4m", SynthClip(64, 48, 1).frames(3))
+    r = run([tmp_path / "one.y4m", "-o=" + str(tmp_path / "o3"), "-s=1", "-a=farn"])
+    assert r.returncode == 0 and "(1 frames, 0 farn flows)" in r.stdout
+    (tmp_path / "l.txt").write_text(f"{tmp_path / 'three.y4m'}\n{tmp_path / 'one.y4m'}\n")
+    r = run([tmp_path / "l.txt", "-o=" + str(tmp_path / "o4"), "-s=5", "-a=farn"])
+    assert r.returncode == 0 and sorted(_files(tmp_path / "o4")) == [".done/one", ".done/three"]
+    data = (tmp_path / "three.y4m").read_bytes()
+    (tmp_path / "trunc.y4m").write_bytes(data[:-100])
+    r = run([tmp_path / "trunc.y4m", "-o=" + str(tmp_path / "o5"), "-s=1", "-a=farn"])
+    assert r.returncode == 0 and sorted(_files(tmp_path / "o5")) == ["trunc/flow_x_00000.jpg", "trunc/flow_y_00000.jpg"]
+    r = run([tmp_path / "three.y4m", "-o=" + str(tmp_path / "o6"), "-s=1", "-a=farn", "-g=4"], {"STUB_DEVICES": "4"})
+    one = run([tmp_path / "three.y4m", "-o=" + str(tmp_path / "o7"), "-s=1", "-a=farn"])
+    assert r.returncode == 0 and one.returncode == 0 and _files(tmp_path / "o6") == _files(tmp_path / "o7")
+    r = run([tmp_path / "three.y4m", "-o=" + str(tmp_path / "o8"), "-s=1", "-a=nv"])
+    assert r.returncode != 0 and "NV hardware flow not enabled, pls recompile" in r.stdout + r.stderr
+
+
 def test_the_stub_is_test_infrastructure_only():
     """Nothing the product builds or loads may know the fake: no CPU path hides behind the C ABI."""
     hits = []
