@@ -71,9 +71,9 @@ DFX_JPEG_HD inline void dfx_jpeg_fdct_islow_1d(I &d0, I &d1, I &d2, I &d3, I &d4
     const int R = 1 << (S - 1);
     I t0 = d0 + d7, t7 = d0 - d7, t1 = d1 + d6, t6 = d1 - d6, t2 = d2 + d5, t5 = d2 - d5, t3 = d3 + d4, t4 = d3 - d4;
     const I t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
-    if (FIRST) {
-        d0 = (t10 + t11) << PASS1;
-        d4 = (t10 - t11) << PASS1;
+    if (FIRST) { /* x 2^PASS1 (libjpeg's LEFT_SHIFT; a multiplication because << of a negative int is undefined before C++20) */
+        d0 = (t10 + t11) * (1 << PASS1);
+        d4 = (t10 - t11) * (1 << PASS1);
     } else {
         d0 = (t10 + t11 + (1 << (PASS1 - 1))) >> PASS1;
         d4 = (t10 - t11 + (1 << (PASS1 - 1))) >> PASS1;

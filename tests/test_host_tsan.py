@@ -73,3 +73,38 @@ def test_whole_pipeline_is_race_free_under_tsan(tmp_path):
                            capture_output=True, text=True, env={**os.environ, "TSAN_OPTIONS": "halt_on_error=0", **env})
         assert "WARNING: ThreadSanitizer" not in r.stderr, (extra_args, env, r.stderr[-4000:])
         assert r.returncode == 0 and "12 videos" in r.stdout, r.stdout + r.stderr[-2000:]
+
+
+def test_whole_pipeline_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """The same pipeline under ASan + UBSan + LeakSanitizer (it found a left shift of a negative int in the shared DCT
+    header).  Lists of clips of unequal sizes and lengths through jpg / png / h5, short FlowBuffers, two device pipelines,
+    host bounding, the resize hand-off and the JPEG fallback."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "denseflow_stub_asan")
+    srcs = [os.path.join(ROOT, "tools", "denseflow.cpp"), os.path.join(ROOT, "tests", "stub_dfx.cpp")] + [
+        os.path.join(ROOT, "src", f) for f in ("common.cpp", "image_io.cpp", "utils.cpp", "h5mini.cpp", "denseflow_gpu.cpp")]
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                        "-I" + os.path.join(ROOT, "include")] + srcs + ["-lpthread", "-lz", "-ldl", "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0 and ("asan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("AddressSanitizer build not available here: " + r.stderr[-300:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = []
+    for i, (w, h, n) in enumerate([(64, 48, 7), (64, 48, 5), (64, 48, 2), (64, 48, 9), (96, 64, 6), (64, 48, 4), (45, 27, 8)]):
+        clip = tmp_path / f"c{i}.y4m"
+        with open(clip, "wb") as f:
+            f.write(f"YUV4MPEG2 W{w} H{h} F30:1 Ip A1:1 Cmono\n".encode())
+            for k in range(n):
+                f.write(b"FRAME\n")
+                f.write(((np.arange(w * h, dtype=np.uint32) * (3 + i) + 11 * k) & 0xFF).astype(np.uint8).tobytes())
+        lines.append(str(clip))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    runs = (([], {}), (["-st=png"], {"DF_BATCH_MAXSIZE": "3"}), (["-st=h5"], {}), (["-g=2"], {"STUB_DEVICES": "2"}),
+            ([], {"DF_HOST_BOUND": "1"}), (["-nw=40", "-nh=30"], {}), ([], {"STUB_JPEG_UNSUPPORTED": "1", "STUB_DELAY_MS": "10"}))
+    for k, (extra_args, env) in enumerate(runs):
+        r = subprocess.run([exe, str(tmp_path / "list.txt"), "-o=" + str(tmp_path / f"o{k}"), "-a=farn", "-s=2"] + extra_args,
+                           capture_output=True, text=True, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1", **env})
+        for mark in ("ERROR: AddressSanitizer", "runtime error", "LeakSanitizer"):
+            assert mark not in r.stderr, (extra_args, env, r.stderr[-3000:])
+        assert r.returncode == 0 and "7 videos" in r.stdout, r.stdout + r.stderr[-2000:]
