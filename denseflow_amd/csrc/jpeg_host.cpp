@@ -70,7 +70,8 @@ size_t jpeg_assemble(const std::vector<unsigned char> &header, const unsigned ch
         size_t ff = 0;
         for (size_t i = 0; i < full; ++i)
             ff += src[i] == 0xFF;
-        if (header.size() + full + ff + (rem ? 2 : 0) + 2 > capacity)
+        const size_t tail = rem ? ((unsigned char)(src[full] | ((1u << (8 - rem)) - 1u)) == 0xFF ? 2 : 1) : 0;
+        if (header.size() + full + ff + tail + 2 > capacity)
             return 0;
     }
     unsigned char *p = dst;

@@ -3,6 +3,7 @@ stuffing must reproduce the shell's host encoder (src/image_io.cpp, imencodeJpeg
 encoder is split into header / entropy-coded segment, the segment is un-stuffed into the plain bit string the device
 produces, and dfxi_jpeg_assemble must rebuild the very same file from it."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -102,3 +103,27 @@ def test_host_encoder_reproduces_the_golden_files(harness):
                 n = harness.hh_encode_jpeg(plane.ctypes.data, plane.shape[1], plane.shape[0], q, buf.ctypes.data, buf.size)
                 assert buf[:n].tobytes() == g[f"{name}_q{q}_file"].tobytes(), (name, q, portable)
     harness.hh_jpeg_force_portable(0)
+
+
+def test_assembly_fuzz_under_sanitizers(tmp_path):
+    """jpeg_assemble (denseflow_amd/csrc/jpeg_host.cpp) on 12 000 random bit strings (all-0xFF, noise, mostly-0xFF), compiled
+    with AddressSanitizer + UBSan: destination buffers of exactly the file size (the capacity check is exact), one byte less
+    refused, correct stuffing and EOI (tests/jpeg_assemble_fuzz.cpp)."""
+    import shutil
+    import subprocess
+
+    from tests.test_host_shell import ROOT
+
+    if shutil.which("g++") is None or not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("needs g++ and the HIP headers")
+    exe = str(tmp_path / "jpeg_fuzz")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-D__HIP_PLATFORM_AMD__",
+                        "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                        os.path.join(ROOT, "tests", "jpeg_assemble_fuzz.cpp"),
+                        os.path.join(ROOT, "denseflow_amd", "csrc", "jpeg_host.cpp")], capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr.lower():
+        pytest.skip("sanitizer build not available: " + r.stderr[-300:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok 12000" in r.stdout, r.stdout + r.stderr[-3000:]
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
