@@ -30,14 +30,15 @@ bool VideoCapture::open(const string &file) {
     string cs = "420";
     char *save = nullptr; // strtok_r: several loader threads (one per device) open clips concurrently
     for (char *tok = strtok_r(line + 9, " \n", &save); tok; tok = strtok_r(nullptr, " \n", &save)) {
+        // strtol saturates where atoi is undefined; anything beyond the engine's limit is rejected below
         if (tok[0] == 'W')
-            w_ = atoi(tok + 1);
+            w_ = (int)std::min<long>(std::max<long>(strtol(tok + 1, nullptr, 10), -1), 1 << 20);
         else if (tok[0] == 'H')
-            h_ = atoi(tok + 1);
+            h_ = (int)std::min<long>(std::max<long>(strtol(tok + 1, nullptr, 10), -1), 1 << 20);
         else if (tok[0] == 'C')
             cs = tok + 1;
     }
-    if (w_ <= 0 || h_ <= 0) {
+    if (w_ <= 0 || h_ <= 0 || w_ > 32768 || h_ > 32768) { // the engine's own limit (dfx_create); also keeps w * h in range
         f_.reset();
         return false;
     }
@@ -102,6 +103,8 @@ static bool pnm_token(FILE *fp, int &v) {
         return false;
     v = 0;
     while (c >= '0' && c <= '9') {
+        if (v > (1 << 24)) // no header field of a usable image is that large; keeps v * 10 in range
+            return false;
         v = v * 10 + (c - '0');
         c = fgetc(fp);
     }
@@ -117,7 +120,8 @@ bool imreadGray(const string &file, Mat &gray) {
     if (fread(magic, 1, 2, fp) != 2 || magic[0] != 'P' || (magic[1] != '5' && magic[1] != '6'))
         return false;
     int w, h, maxv;
-    if (!pnm_token(fp, w) || !pnm_token(fp, h) || !pnm_token(fp, maxv) || maxv != 255 || w <= 0 || h <= 0)
+    if (!pnm_token(fp, w) || !pnm_token(fp, h) || !pnm_token(fp, maxv) || maxv != 255 || w <= 0 || h <= 0 || w > 32768 ||
+        h > 32768)
         return false;
     gray.create(Size(w, h), CV_8UC1);
     if (magic[1] == '5')

@@ -108,3 +108,29 @@ def test_whole_pipeline_under_address_and_undefined_behaviour_sanitizers(tmp_pat
         for mark in ("ERROR: AddressSanitizer", "runtime error", "LeakSanitizer"):
             assert mark not in r.stderr, (extra_args, env, r.stderr[-3000:])
         assert r.returncode == 0 and "7 videos" in r.stdout, r.stdout + r.stderr[-2000:]
+    # malformed inputs: refused or read as far as they go, never a sanitizer report, never a hang
+    rng = np.random.default_rng(3)
+    bad = {
+        "huge": b"YUV4MPEG2 W2000000000 H2000000000 F30:1 Ip A1:1 Cmono\nFRAME\n" + b"\0" * 100,
+        "digits": b"YUV4MPEG2 W" + b"9" * 40 + b" H48 Cmono\nFRAME\n",
+        "neg": b"YUV4MPEG2 W-5 H48 F30:1 Cmono\nFRAME\n" + b"\0" * 100,
+        "zero": b"YUV4MPEG2 W0 H0 Cmono\nFRAME\n",
+        "nofields": b"YUV4MPEG2\nFRAME\n",
+        "longline": b"YUV4MPEG2 " + b"X" * 5000 + b"\nFRAME\n",
+        "c420trunc": b"YUV4MPEG2 W64 H48 F30:1 C420\nFRAME\n" + b"\1" * (64 * 48) + b"\2" * 100,
+        "frameparams": b"YUV4MPEG2 W8 H8 Cmono\n" + (b"FRAME Ip\n" + b"\1" * 64) * 3,
+        "garbage": rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(),
+    }
+    for name, data in bad.items():
+        (tmp_path / f"{name}.y4m").write_bytes(data)
+        r = subprocess.run([exe, str(tmp_path / f"{name}.y4m"), "-o=" + str(tmp_path / "bad"), "-a=farn", "-s=1"],
+                           capture_output=True, text=True, timeout=60, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
+        for mark in ("AddressSanitizer", "runtime error"):
+            assert mark not in r.stderr, (name, r.stderr[-3000:])
+        assert r.returncode == 0 or "cannot open video_path stream" in r.stdout + r.stderr, (name, r.stdout, r.stderr[-500:])
+    pg = tmp_path / "pgms"
+    pg.mkdir()
+    (pg / "img_00000.pgm").write_bytes(b"P5\n" + b"9" * 30 + b" 4\n255\n" + b"\0" * 16)
+    r = subprocess.run([exe, str(pg), "--if", "-o=" + str(tmp_path / "badp"), "-a=farn", "-s=1"], capture_output=True,
+                       text=True, timeout=60, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
