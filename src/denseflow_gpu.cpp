@@ -159,6 +159,10 @@ bool DenseFlow::check_param() {
         cout << "height and width cannot < 0!" << endl;
         return false;
     }
+    if (new_height > 32768 || new_width > 32768 || new_short > 32768) { // the engine's limit (dfx_create); not in the reference
+        cout << "height and width cannot > 32768!" << endl;
+        return false;
+    }
     if (new_short > 0 && new_height + new_width != 0) {
         cout << "do not set height and width when set short!" << endl;
         return false;
