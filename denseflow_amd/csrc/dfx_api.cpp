@@ -284,7 +284,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         *ticket = 0;
     else
         (void)dfx_finish_tails(c, 0, -1); // synchronous entry points never run beside a deferred tail
-    if (n_frames < 0 || step == 0)
+    if (n_frames < 0 || step == 0 || step < -(1 << 30) || step > (1 << 30)) // (|INT_MIN| is not an int)
         return dfx_fail(c, DFX_ERR_INVALID, "n_frames must be >= 0 and step non-zero");
     const int astep = std::abs(step);
     // The FlowBuffer's pairs as (frame a, frame b), frame ids counted over the whole buffer.  One clip: pair i is

@@ -155,6 +155,10 @@ bool DenseFlow::check_param() {
         cout << "bound should > 0!" << endl;
         return false;
     }
+    if (step < -(1 << 24) || step > (1 << 24)) { // keeps |step| and frame-index arithmetic in range; not in the reference
+        cout << "step out of range!" << endl;
+        return false;
+    }
     if (new_height < 0 || new_width < 0 || new_short < 0) {
         cout << "height and width cannot < 0!" << endl;
         return false;

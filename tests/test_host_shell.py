@@ -101,6 +101,8 @@ def test_cli_error_behaviour(built, tmp_path):
     r = subprocess.run([built, str(clip), "-o=" + str(tmp_path), "-s=1", "-nw=2000000000", "-nh=2000000000"],
                        capture_output=True, text=True)  # beyond the engine's limit: refused before anything is sized by it
     assert r.returncode == 1 and "height and width cannot > 32768!" in r.stdout
+    r = subprocess.run([built, str(clip), "-o=" + str(tmp_path), "-s=-2147483648"], capture_output=True, text=True)
+    assert r.returncode == 1 and "step out of range!" in r.stdout
     r = subprocess.run([built, str(clip), "-o=" + str(tmp_path), "-s=abc"], capture_output=True, text=True)
     assert r.returncode == 0 and "can not convert" in r.stdout  # parse errors: print, exit 0 (tools/denseflow.cpp:30-33)
     r = subprocess.run([built, str(tmp_path / "missing.y4m"), "-o=" + str(tmp_path), "-s=1"], capture_output=True,
