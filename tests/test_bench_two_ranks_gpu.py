@@ -60,3 +60,17 @@ def test_self_launched_two_ranks():
         out = json.loads(lines[0])
         assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["config"]["pairs_per_step"] == pairs
         assert out["value"] > 0 and out["data"] == "synthetic"
+
+
+def test_self_launched_two_ranks_each_with_a_list_of_short_clips():
+    """--clips: every rank joins its share of a list of short clips into one FlowBuffer (dfx_next_segments) — BASELINE
+    configs[3] sharded over the GPUs of a node."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DFX_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "12",
+           "--clips", "3", "--width", "224", "--height", "224", "--no-cpu-baseline", "--no-pcie", "--no-others"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["pairs_per_step"] == 2 * 3 * 11
+    assert "3 clips per GPU" in out["config"]["workload"] and out["value"] > 0
