@@ -126,7 +126,7 @@ def test_a_list_of_short_clips_is_joined_without_changing_a_byte(stub, tmp_path,
     outs, groups = {}, {}
     for tag, extra in (("joined", {}), ("single", {"DF_NO_JOIN": "1"})):
         r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / tag), "-a=farn", "-s=2", "-b=20", "-st=" + st],
-                 {**env, **extra, "DF_TRACE": "1", "STUB_DELAY_MS": "15"})  # a slow "device": the loader runs ahead
+                 {**env, **extra, "DF_TRACE": "1", "STUB_DELAY_MS": "40"})  # a slow "device": the loader runs ahead
         outs[tag] = _files(tmp_path / tag)
         groups[tag] = [int(g) for g in re.findall(r"frames of (\d+) FlowBuffer", r.stderr)]
     assert max(groups["single"]) == 1 and max(groups["joined"]) > 1, groups
@@ -147,9 +147,9 @@ def test_joining_really_happens_when_clips_are_waiting(stub, tmp_path):
         write_y4m(tmp_path / f"c{i}.y4m", SynthClip(32, 24, i).frames(6))
         lines.append(str(tmp_path / f"c{i}.y4m"))
     (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
-    # a "device" that takes 30 ms per call: while the first call runs the loader queues the other clips, so the next
+    # a "device" that takes 60 ms per call: while the first call runs the loader queues the other clips, so the next
     # call must take several of them along
-    r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1"], {"DF_TRACE": "1", "STUB_DELAY_MS": "30"})
+    r = _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "o"), "-a=farn", "-s=1"], {"DF_TRACE": "1", "STUB_DELAY_MS": "60"})
     sizes = [int(g) for g in re.findall(r"frames of (\d+) FlowBuffer", r.stderr)]
     assert max(sizes) > 1 and sum(sizes) == 24, sizes
 
