@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Pin the save stage's encoders to OpenCV's own bytes — runs on ANY machine with a plain `cv2` (no CUDA needed; e.g.
-`pip install opencv-python`).  The JPEG / PNG writers of this repository are already held to libjpeg-turbo's and libpng's
+"""Pin the stages the reference runs on the CPU — the save stage's encoders and the loader's gray conversion + resize — to
+OpenCV's own output.  Runs on ANY machine with a plain `cv2` (no CUDA needed; e.g. `pip install opencv-python`).  The JPEG / PNG writers of this repository are already held to libjpeg-turbo's and libpng's
 files (tests/test_jpeg_libjpeg_pin.py, tests/test_png_libpng_pin.py), on the understanding that cv::imencode drives those
 libraries with their defaults (JPEG) and with SUB filter + Z_BEST_SPEED + Z_RLE (PNG): this script replaces that
 understanding with cv2's output.  It encodes the planes / images of tests/golden/jpeg_golden.npz and png_golden.npz with
@@ -10,9 +10,18 @@ understanding with cv2's output.  It encodes the planes / images of tests/golden
 
 and writes tests/golden/opencv_imencode.npz (files + cv2.getBuildInformation()); tests/test_opencv_pin.py::
 test_encoders_reproduce_cv2_imencode then holds the host encoders (and, on the GPU box, the device JPEG encoder) to those
-bytes.  Nothing here imports the product.
+bytes.
 
-    python scripts/pin_imencode_against_opencv.py [--out tests/golden]"""
+Frame preparation ("parity unpinned" today): the reference's loader calls, on the CPU,
+
+    cvtColor(frame, gray, COLOR_BGR2GRAY)     (/root/reference/src/denseflow_gpu.cpp:163)
+    cv::resize(gray, resized, size)            (:169, default INTER_LINEAR)
+
+This script applies exactly those to the sources of tests/golden/prepare_golden.npz and writes
+tests/golden/opencv_prepare.npz; test_frame_preparation_reproduces_cv2 then holds the oracle (CPU) and the device kernel
+(GPU) to cv2's pixels, bit for bit.  Nothing here imports the product.
+
+    python scripts/pin_cpu_stages_against_opencv.py [--out tests/golden]"""
 import argparse
 import os
 import sys
@@ -48,6 +57,21 @@ def main():
             print("png", k[:-6], pg[k].shape, blob["png_" + k[:-6]].size, "bytes")
     np.savez_compressed(os.path.join(args.out, "opencv_imencode.npz"), **blob)
     print("wrote", os.path.join(args.out, "opencv_imencode.npz"), "with OpenCV", cv2.__version__)
+
+    prep = {"version": np.frombuffer(cv2.__version__.encode(), np.uint8)}
+    g = np.load(os.path.join(ROOT, "tests", "golden", "prepare_golden.npz"))
+    for k in g.files:
+        if not k.endswith("_src"):
+            continue
+        src, want = np.ascontiguousarray(g[k]), g[k[:-4] + "_dst"]
+        gray = cv2.cvtColor(src, cv2.COLOR_BGR2GRAY) if src.ndim == 3 else src
+        dh, dw = want.shape
+        out = cv2.resize(gray, (dw, dh)) if gray.shape != (dh, dw) else gray
+        prep[k[:-4]] = np.ascontiguousarray(out)
+        print("prepare", k[:-4], src.shape, "->", out.shape, "differs from the committed oracle golden in",
+              int(np.count_nonzero(out != want)), "pixels")
+    np.savez_compressed(os.path.join(args.out, "opencv_prepare.npz"), **prep)
+    print("wrote", os.path.join(args.out, "opencv_prepare.npz"))
 
 
 if __name__ == "__main__":

@@ -45,7 +45,7 @@ def test_hip_path_reproduces_opencv_cuda(dfx, algo):
 def _imencode_golden():
     p = os.path.join(GOLDEN, "opencv_imencode.npz")
     if not os.path.exists(p):
-        pytest.skip(f"{p} absent: run scripts/pin_imencode_against_opencv.py where any cv2 exists (the encoders are pinned "
+        pytest.skip(f"{p} absent: run scripts/pin_cpu_stages_against_opencv.py where any cv2 exists (the encoders are pinned "
                     "to libjpeg-turbo / libpng directly until then: tests/test_jpeg_libjpeg_pin.py, test_png_libpng_pin.py)")
     return np.load(p)
 
@@ -95,3 +95,30 @@ def test_device_jpeg_reproduces_cv2_imencode(dfx):
             plane = jg[k[4:] + "_plane"]
             with dfx.FlowEngine(plane.shape[1], plane.shape[0], "farn") as eng:
                 assert eng.encode_jpeg([plane], 95)[0] == g[k].tobytes(), k
+
+
+def _prepare_golden():
+    p = os.path.join(GOLDEN, "opencv_prepare.npz")
+    if not os.path.exists(p):
+        pytest.skip(f"{p} absent: run scripts/pin_cpu_stages_against_opencv.py where any cv2 exists (frame preparation is "
+                    "parity unpinned until then)")
+    return np.load(p), np.load(os.path.join(GOLDEN, "prepare_golden.npz"))
+
+
+def test_frame_preparation_reproduces_cv2(oracle):
+    """cvtColor(BGR2GRAY) + cv::resize(INTER_LINEAR) as the reference's loader calls them (src/denseflow_gpu.cpp:163, :169):
+    the oracle's restatement against cv2's pixels, bit for bit (integer work)."""
+    cv, g = _prepare_golden()
+    for name in [k for k in cv.files if k != "version"]:
+        want = cv[name]
+        got = oracle.prepare_frame(g[name + "_src"], want.shape[1], want.shape[0])
+        assert np.array_equal(got, want), (name, int(np.count_nonzero(got != want)))
+
+
+@pytest.mark.gpu
+def test_device_frame_preparation_reproduces_cv2(dfx):
+    cv, g = _prepare_golden()
+    for name in [k for k in cv.files if k != "version"]:
+        want = cv[name]
+        with dfx.FlowEngine(want.shape[1], want.shape[0], "farn") as eng:
+            assert np.array_equal(eng.prepare_frames([g[name + "_src"]])[0], want), name
