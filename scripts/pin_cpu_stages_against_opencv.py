@@ -19,7 +19,13 @@ Frame preparation ("parity unpinned" today): the referen
 
 This script applies exactly those to the sources of tests/golden/prepare_golden.npz and writes
 tests/golden/opencv_prepare.npz; test_frame_preparation_reproduces_cv2 then holds the oracle (CPU) and the device kernel
-(GPU) to cv2's pixels, bit for bit.  Nothing here imports the product.
+(GPU) to cv2's pixels, bit for bit.
+
+The CPU comparator of bench.py (`cpu_baseline`: cv::optflow::DualTVL1OpticalFlow restated in oracle/cpu_tvl1_baseline.c): when
+the installed cv2 has the contrib modules (`pip install opencv-contrib-python`) the same three synthetic pairs as
+scripts/pin_against_opencv.py uses are run through cv2.optflow.DualTVL1OpticalFlow_create().calc and written to
+tests/golden/opencv_cpu_tvl1.npz (tests/test_opencv_pin.py::test_cpu_baseline_port_reproduces_opencv_cpu_dualtvl1).
+Nothing here imports the product.
 
     python scripts/pin_cpu_stages_against_opencv.py [--out tests/golden]"""
 import argparse
@@ -72,6 +78,24 @@ def main():
               int(np.count_nonzero(out != want)), "pixels")
     np.savez_compressed(os.path.join(args.out, "opencv_prepare.npz"), **prep)
     print("wrote", os.path.join(args.out, "opencv_prepare.npz"))
+
+    if hasattr(cv2, "optflow") and hasattr(cv2.optflow, "DualTVL1OpticalFlow_create"):
+        sys.path.insert(0, ROOT)
+        from denseflow_amd.synth import SynthClip  # numpy only
+
+        tv = {"opencv_version": np.array(cv2.__version__)}
+        for (w, h, seed, t0, t1) in [(64, 48, 3, 0, 1), (224, 224, 1, 0, 1), (224, 224, 1, 3, 1)]:  # pin_against_opencv.py's
+            clip = SynthClip(w, h, seed)
+            name = f"synth_{w}x{h}_s{seed}_t{t0}_{t1}"
+            a, b = clip.frame(t0), clip.frame(t1)
+            tv[name + "_f0"], tv[name + "_f1"] = a, b
+            tv[name + "_flow"] = cv2.optflow.DualTVL1OpticalFlow_create().calc(a, b, None).astype(np.float32)
+            print("cpu DualTVL1", name, float(np.abs(tv[name + "_flow"]).max()))
+        np.savez_compressed(os.path.join(args.out, "opencv_cpu_tvl1.npz"), **tv)
+        print("wrote", os.path.join(args.out, "opencv_cpu_tvl1.npz"))
+    else:
+        print("cv2.optflow absent (plain opencv-python): the CPU DualTVL1 comparator stays unpinned; "
+              "opencv-contrib-python has it")
 
 
 if __name__ == "__main__":
