@@ -79,9 +79,25 @@ def main():
     np.savez_compressed(os.path.join(args.out, "opencv_prepare.npz"), **prep)
     print("wrote", os.path.join(args.out, "opencv_prepare.npz"))
 
+    sys.path.insert(0, ROOT)
+    from denseflow_amd.synth import SynthClip  # numpy only
+
+    # CROSS-CHECK, not a pin: CPU cv2.calcOpticalFlowFarneback with the parameters cv::cuda::FarnebackOpticalFlow::create()
+    # defaults to (5 levels, 0.5, window 13, 10 iterations, polyN 5, sigma 1.1, flags 0).  The CUDA class is a port of this
+    # function with its own border and blur details, so the flows agree closely, not to 1e-3; a large gap to the oracle
+    # would still expose a structural misreading of Appendix B.
+    fb = {"opencv_version": np.array(cv2.__version__)}
+    for (w, h, seed, t0, t1) in [(64, 48, 3, 0, 1), (224, 224, 1, 0, 1), (320, 200, 6, 0, 2)]:
+        clip = SynthClip(w, h, seed)
+        name = f"synth_{w}x{h}_s{seed}_t{t0}_{t1}"
+        a, b = clip.frame(t0), clip.frame(t1)
+        fb[name + "_f0"], fb[name + "_f1"] = a, b
+        fb[name + "_flow"] = cv2.calcOpticalFlowFarneback(a, b, None, 0.5, 5, 13, 10, 5, 1.1, 0).astype(np.float32)
+        print("cpu Farneback", name, float(np.abs(fb[name + "_flow"]).max()))
+    np.savez_compressed(os.path.join(args.out, "opencv_cpu_farneback.npz"), **fb)
+    print("wrote", os.path.join(args.out, "opencv_cpu_farneback.npz"))
+
     if hasattr(cv2, "optflow") and hasattr(cv2.optflow, "DualTVL1OpticalFlow_create"):
-        sys.path.insert(0, ROOT)
-        from denseflow_amd.synth import SynthClip  # numpy only
 
         tv = {"opencv_version": np.array(cv2.__version__)}
         for (w, h, seed, t0, t1) in [(64, 48, 3, 0, 1), (224, 224, 1, 0, 1), (224, 224, 1, 3, 1)]:  # pin_against_opencv.py's

@@ -122,3 +122,18 @@ def test_device_frame_preparation_reproduces_cv2(dfx):
         want = cv[name]
         with dfx.FlowEngine(want.shape[1], want.shape[0], "farn") as eng:
             assert np.array_equal(eng.prepare_frames([g[name + "_src"]])[0], want), name
+
+
+def test_oracle_is_close_to_opencv_cpu_farneback(oracle):
+    """A cross-check, not a pin: CPU cv2.calcOpticalFlowFarneback (the function the CUDA class was ported from) with the CUDA
+    class's default parameters.  Border handling and blur details differ, so the bar is loose — interior mean-abs 0.05 px —
+    but a structural misreading of SURVEY.md Appendix B (pyramid, polynomial expansion, update equations) would be far off."""
+    p = os.path.join(GOLDEN, "opencv_cpu_farneback.npz")
+    if not os.path.exists(p):
+        pytest.skip(f"{p} absent: run scripts/pin_cpu_stages_against_opencv.py where any cv2 exists")
+    g = np.load(p)
+    for k in [k for k in g.files if k.endswith("_flow")]:
+        f0, f1, want = g[k[:-5] + "_f0"], g[k[:-5] + "_f1"], g[k]
+        got = oracle.farneback_calc(f0, f1)
+        m = 16  # away from the borders, where the two implementations extrapolate differently
+        assert np.abs(got[m:-m, m:-m] - want[m:-m, m:-m]).mean() <= 0.05, k
