@@ -72,3 +72,31 @@ def test_reciprocal_quantisation_is_libjpegs_integer_division(harness):
     samples give |output| <= 8 * 1024 * 1.39 < 12000)."""
     harness.hh_jpeg_quantise_mismatches.restype = C.c_longlong
     assert harness.hh_jpeg_quantise_mismatches(40000) == 0
+
+
+def test_random_planes_against_libjpeg(harness):
+    """Property form of the live pin: random sizes (1 ... 150 per side: ragged right / bottom blocks of every width), every
+    quality 1 ... 100, contents from constant to noise; scalar and vector transforms."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    pytest.importorskip("PIL.Image")
+
+    @settings(max_examples=150, deadline=None)
+    @given(w=st.integers(1, 150), h=st.integers(1, 150), q=st.integers(1, 100), kind=st.integers(0, 3), seed=st.integers(0, 2 ** 31))
+    def check(w, h, q, kind, seed):
+        rng = np.random.default_rng(seed)
+        if kind == 0:
+            plane = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 1:
+            plane = np.full((h, w), int(rng.integers(0, 256)), np.uint8)
+        elif kind == 2:
+            yy, xx = np.mgrid[0:h, 0:w]
+            plane = np.clip(128 + 100 * np.sin(xx / 7.0 + seed % 7) * np.cos(yy / 5.0) + rng.normal(0, 3, (h, w)), 0, 255).astype(np.uint8)
+        else:  # saturated: 0 / 255 only (the extreme coefficients)
+            plane = (rng.random((h, w)) < 0.5).astype(np.uint8) * 255
+        want = _libjpeg(plane, q)
+        assert _host(harness, plane, q) == want
+        assert _host(harness, plane, q, portable=1) == want
+
+    check()

@@ -75,3 +75,37 @@ def test_encoded_flow_png_is_libpngs_file(harness, oracle):
     rgb = np.array(Image.open(io.BytesIO(buf[:n].tobytes())))
     assert rgb.shape == (h, w, 3)
     assert buf[:n].tobytes() == libpng_ref.imencode_png(rgb[..., ::-1])
+
+
+def test_random_images_against_libpng(harness):
+    """Property form of the live pin: random sizes (1 ... 200 per side, so both libpng's small-image rules and multi-IDAT
+    streams occur), gray and BGR, contents from constant to noise."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from tests import libpng_ref
+
+    if libpng_ref.load() is None:
+        pytest.skip("no libpng16 on this machine")
+
+    @settings(max_examples=120, deadline=None)
+    @given(w=st.integers(1, 200), h=st.integers(1, 200), ch=st.sampled_from([1, 3]), kind=st.integers(0, 3),
+           seed=st.integers(0, 2 ** 31))
+    def check(w, h, ch, kind, seed):
+        rng = np.random.default_rng(seed)
+        shape = (h, w) if ch == 1 else (h, w, 3)
+        if kind == 0:
+            img = rng.integers(0, 256, shape, dtype=np.uint8)
+        elif kind == 1:
+            img = np.full(shape, int(rng.integers(0, 256)), np.uint8)
+        elif kind == 2:  # smooth ramps with a little noise: long and short RLE runs mixed
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = (xx * 3 + yy * 2) % 256 + rng.integers(0, 2, (h, w))
+            img = np.clip(base if ch == 1 else np.stack([base, 255 - base, base // 2], -1), 0, 255).astype(np.uint8)
+        else:  # mostly constant with sparse spikes
+            img = np.full(shape, 128, np.uint8)
+            mask = rng.random(shape[:2]) < 0.02
+            img[mask] = 255
+        assert _mine(harness, img) == libpng_ref.imencode_png(img)
+
+    check()
