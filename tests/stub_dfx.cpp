@@ -78,6 +78,11 @@ struct Prepared {
     DfxPairs pairs;
 };
 int prepare(dfx_context *c, const uint8_t *const *frames, size_t pitch, int n_frames, int step, Prepared &out) {
+    if (const char *f = std::getenv("STUB_FAIL_SUBMIT")) // the n-th library call fails (a HIP error in the real library)
+        if ((unsigned long long)std::atoll(f) == c->next_ticket) {
+            c->next_segments.clear();
+            return fail(c, DFX_ERR_HIP, "stub: hipMemcpyAsync failed");
+        }
     if (const char *ms = std::getenv("STUB_DELAY_MS")) // a slow "device": lets the loader run ahead (joining tests)
         std::this_thread::sleep_for(std::chrono::milliseconds(std::atoi(ms)));
     std::vector<int> seg;
@@ -268,7 +273,14 @@ int dfx_submit_batch_jpeg(dfx_handle h, const uint8_t *const *frames, size_t fra
     return DFX_OK;
 }
 
-int dfx_wait(dfx_handle, uint64_t) { return DFX_OK; }
+int dfx_wait(dfx_handle h, uint64_t ticket) {
+    // STUB_FAIL_WAIT=<ticket>: the tail of that FlowBuffer "fails" (a deferred download error in the real library): the
+    // shell must stop without writing its flows, without marking the video done, and without hanging a stage
+    if (const char *f = std::getenv("STUB_FAIL_WAIT"))
+        if (ticket != 0 && (uint64_t)std::atoll(f) == ticket)
+            return fail(h, DFX_ERR_HIP, "stub: deferred download failed");
+    return DFX_OK;
+}
 
 int dfx_host_alloc(void **ptr, size_t bytes) {
     *ptr = std::malloc(bytes ? bytes : 1);

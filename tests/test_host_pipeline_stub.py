@@ -281,6 +281,49 @@ def test_degenerate_inputs_end_cleanly(stub, tmp_path):
     assert r.returncode != 0 and "NV hardware flow not enabled, pls recompile" in r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("ticket", [1, 2, 3])
+def test_a_failed_tail_stops_the_run_without_garbage_or_done_records(stub, tmp_path, ticket):
+    """dfx_wait reports a failed deferred download for one FlowBuffer: nothing of that FlowBuffer or of a later
+    one may reach the disk, its video must not be marked done, the process ends with the error and does not hang."""
+    lines = []
+    for i in range(4):
+        write_y4m(tmp_path / f"v{i}.y4m", SynthClip(48, 32, 70 + i).frames(9))
+        lines.append(str(tmp_path / f"v{i}.y4m"))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    good = tmp_path / "good"
+    _run(stub, [tmp_path / "list.txt", "-o=" + str(good), "-a=farn", "-s=1"], {"DF_NO_JOIN": "1", "DF_BATCH_MAXSIZE": "5"})
+    want = _files(good)
+    r = subprocess.run([stub, str(tmp_path / "list.txt"), "-o=" + str(tmp_path / "bad"), "-a=farn", "-s=1"],
+                       capture_output=True, text=True, timeout=60,
+                       env={**os.environ, "DF_NO_JOIN": "1", "DF_BATCH_MAXSIZE": "5", "STUB_FAIL_WAIT": str(ticket)})
+    assert r.returncode != 0 and "deferred download failed" in r.stdout + r.stderr
+    got = _files(tmp_path / "bad")
+    # every file that was written is a correct one (nothing of the failed FlowBuffer, no garbage) ...
+    assert all(f in want and got[f] == want[f] for f in got), sorted(set(got) - set(want))
+    # ... the run did not finish, and the video of the failed FlowBuffer (two FlowBuffers per video here) is not marked done
+    assert len(got) < len(want)
+    assert f".done/v{(ticket - 1) // 2}" not in got
+
+
+def test_a_failed_library_call_ends_the_run_with_its_message(stub, tmp_path):
+    """dfx_submit_batch* returns an error for the third FlowBuffer: the message reaches the user, the exit status is non-zero,
+    what was written before is intact, the video being processed is not marked done, nothing hangs."""
+    lines = []
+    for i in range(3):
+        write_y4m(tmp_path / f"v{i}.y4m", SynthClip(48, 32, 80 + i).frames(9))
+        lines.append(str(tmp_path / f"v{i}.y4m"))
+    (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+    env = {"DF_NO_JOIN": "1", "DF_BATCH_MAXSIZE": "5"}
+    _run(stub, [tmp_path / "list.txt", "-o=" + str(tmp_path / "good"), "-a=farn", "-s=1"], env)
+    want = _files(tmp_path / "good")
+    r = subprocess.run([stub, str(tmp_path / "list.txt"), "-o=" + str(tmp_path / "bad"), "-a=farn", "-s=1"],
+                       capture_output=True, text=True, timeout=60, env={**os.environ, **env, "STUB_FAIL_SUBMIT": "3"})
+    assert r.returncode != 0 and "hipMemcpyAsync failed" in r.stdout + r.stderr
+    got = _files(tmp_path / "bad")
+    assert all(f in want and got[f] == want[f] for f in got) and len(got) < len(want)
+    assert ".done/v1" not in got and ".done/v2" not in got
+
+
 def test_the_stub_is_test_infrastructure_only():
     """Nothing the product builds or loads may know the fake: no CPU path hides behind the C ABI."""
     hits = []
