@@ -31,6 +31,13 @@ build/denseflow: tools/denseflow.cpp build/libzzdenseflow.a $(LIB)
 oracle:
 	$(MAKE) -C oracle
 
+# CPU suite (oracle, host logic, encoders vs libjpeg / libpng, the host pipeline against the test-only ABI fake, sanitizers);
+# `make check-gpu` on an MI355X box: parity through the C ABI
+check: lib host oracle
+	python -m pytest tests -q -m "not gpu"
+check-gpu: lib host oracle
+	python -m pytest tests -q -m gpu
+
 clean:
 	rm -rf build $(LIB); $(MAKE) -C oracle clean
-.PHONY: all lib host oracle clean
+.PHONY: all lib host oracle clean check check-gpu
