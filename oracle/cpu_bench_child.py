@@ -86,12 +86,11 @@ def main():
     O.build()
     if kind == "cpu_tvl1":
         fn = lambda a, b: O.cpu_tvl1_calc(a, b, native=True)
-        what = "oracle/cpu_tvl1_baseline.c (CPU cv::optflow::DualTVL1OpticalFlow restatement, create() defaults: " \
-               "10 outer x 30 inner iterations, 5x5 median, cubic remap), gcc -O3 -march=native, OpenMP"
+        what = "oracle/cpu_tvl1_baseline.c (CPU cv::optflow::DualTVL1OpticalFlow port, create() defaults), -O3 -march=native"
     else:
         base = {"tvl1": O.tvl1_calc, "farn": O.farneback_calc, "brox": O.brox_calc}[kind]
         fn = lambda a, b: base(a, b, threads=len(cpus))
-        what = f"oracle/ ({kind}, cv::cuda semantics, the parity oracle), gcc -O2, OpenMP"
+        what = f"oracle/ ({kind}, cv::cuda semantics, the parity oracle), -O2"
     t0 = time.perf_counter()
     fn(frames[0], frames[1])  # warm-up: thread team, page faults, table construction
     t1 = time.perf_counter() - t0
@@ -111,8 +110,8 @@ def main():
         "runs": runs,
         "spread": (runs[2] - runs[0]) / runs[1],
         "sample": f"median of 3 runs over {n} consecutive pairs of the same {w}x{h} clip; {what}; "
-                  f"{len(cpus)} threads pinned one per physical core ({len(allowed)} logical CPUs visible, "
-                  f"cgroup CPU quota {quota if quota is not None else 'none'})",
+                  f"{len(cpus)} OpenMP threads pinned one per physical core ({len(allowed)} logical CPUs visible, "
+                  f"cgroup quota {quota if quota is not None else 'none'})",
     }))
 
 

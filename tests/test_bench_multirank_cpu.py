@@ -107,3 +107,37 @@ def test_self_launch_propagates_a_failing_rank():
                         "--frames", "9", "--split", "clip", "--step", "0", "--no-cpu-baseline"],
                        capture_output=True, text=True, env=env, timeout=120, cwd=ROOT)
     assert r.returncode != 0  # shard_pairs rejects step 0 on every rank
+
+
+def test_full_line_schema_and_size():
+    """The N = 1 line as the driver records it (BENCH_r03.parsed.config kept scalars only and the 8 KB
+    stdout tail cut the line).  DFX_BENCH_STUB=full walks the stub engine through EVERY leg — PCIe-inclusive, the other
+    BASELINE configurations, the CPU comparator's real code on a tiny sample — so the schema is the measured line's:
+    every FLAT_KEYS entry is a float directly under `config`, the joined 224x224 leg is 64 clips (BASELINE configs[3]'s
+    per-GPU share), and the whole line is under 6 KB."""
+    import math
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    env = dict(os.environ, DFX_BENCH_STUB="full")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert len(lines[0]) < 6144, len(lines[0])
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    for k in bench.FLAT_KEYS:
+        if k.endswith("traffic_frac"):
+            continue  # PMC-derived: only where profiles/pmc_traffic.json has the algorithm at this size
+        assert isinstance(cfg.get(k), float) and math.isfinite(cfg[k]), (k, cfg.get(k))
+    assert all(not isinstance(v, (dict, list)) or k in ("pcie_inclusive", "other_workloads") for k, v in cfg.items())
+    legs = {leg["key"]: leg for leg in cfg["other_workloads"]}
+    assert set(legs) == {"farn_1080p", "tvl1_224", "tvl1_224x64", "brox_4k_s2"}
+    assert "x 64 in one FlowBuffer" in legs["tvl1_224x64"]["workload"] and "19136 pairs/step" in legs["tvl1_224x64"]["workload"]
+    for top in ("roofline", "cpu_baseline"):
+        assert isinstance(out[top], dict)
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
