@@ -87,6 +87,38 @@ def lib():
     return L
 
 
+_FMA_LIB_PATH = os.path.join(_HERE, "_native", "liboracle_fma.so")
+
+
+def build_fma() -> str:
+    """The same oracle sources with FMA contraction allowed (-ffp-contract=fast -mfma): what nvcc does by default for
+    the real cudaoptflow kernels.  A rounding-only variant of the oracle, used to anchor the tolerance bands
+    of tests/flow_stats.py in live data and by scripts/oracle_variants.py; never the parity oracle."""
+    srcs = [os.path.join(_HERE, f) for f in ("tvl1_oracle.c", "farneback_oracle.c", "brox_oracle.c", "quant_oracle.c",
+                                              "prepare_oracle.c", "cpu_tvl1_baseline.c")]
+    if not os.path.exists(_FMA_LIB_PATH) or any(os.path.getmtime(x) > os.path.getmtime(_FMA_LIB_PATH) for x in srcs):
+        os.makedirs(os.path.dirname(_FMA_LIB_PATH), exist_ok=True)
+        subprocess.run(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=fast", "-mfma",
+                        "-D_GNU_SOURCE", "-o", _FMA_LIB_PATH] + srcs + ["-lm"], check=True)
+    return _FMA_LIB_PATH
+
+
+class fma_build:
+    """with oracle_py.fma_build(): every *_calc of this module runs the FMA-contracted build of the same sources."""
+
+    def __enter__(self):
+        global _lib
+        self._old = lib()
+        L = C.CDLL(build_fma())
+        _bind_all(L)
+        _lib = L
+        return self
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self._old
+
+
 def _bind_all(L):
     L.orc_set_variant.argtypes = [C.c_int]
     L.orc_get_variant.restype = C.c_int
