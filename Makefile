@@ -18,7 +18,11 @@ $(LIB): $(CSRC) $(CHDR)
 	@mkdir -p denseflow_amd/lib
 	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -Iinclude -o $@ $(CSRC)
 
-host: build/libzzdenseflow.a build/denseflow
+host: build/libzzdenseflow.a build/denseflow build/dfx_prof
+# the torch-free process rocprofv3 profiles (C ABI only; measurement tooling)
+build/dfx_prof: tools/dfx_prof.cpp include/dfx.h $(LIB)
+	@mkdir -p build
+	$(CXX) $(CXXFLAGS) -o $@ tools/dfx_prof.cpp -Ldenseflow_amd/lib -ldfx -Wl,-rpath,'$$ORIGIN/../denseflow_amd/lib' -Wl,-rpath,/opt/rocm/lib
 build/%.o: src/%.cpp $(wildcard include/*.h)
 	@mkdir -p build
 	$(CXX) $(CXXFLAGS) -c $< -o $@

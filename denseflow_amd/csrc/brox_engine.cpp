@@ -101,8 +101,8 @@ int BroxEngine::create() {
     HIPCHK(c, hipMalloc(&d_planes, (size_t)slot_stride * B * sizeof(float)));
     HIPCHK(c, hipMalloc(&d_pairs, sizeof(PairDesc) * B));
     HIPCHK(c, hipHostMalloc(&h_pairs_pinned, sizeof(PairDesc) * B, hipHostMallocDefault));
-    HIPCHK(c, hipEventCreate(&ev[0]));
-    HIPCHK(c, hipEventCreate(&ev[1]));
+    HIPCHK(c, hipEventCreateWithFlags(&ev[0], dfx_event_flags(c, true)));
+    HIPCHK(c, hipEventCreateWithFlags(&ev[1], dfx_event_flags(c, true)));
     return ensure_frame_slots(B + 1);
 }
 

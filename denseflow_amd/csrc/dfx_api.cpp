@@ -610,7 +610,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         }
         HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_compute[par(k)], c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream)); // the engines' statistics read-backs are complete
+        HIPCHK(c, dfx_stream_wait(c, c->stream)); // the engines' statistics read-backs are complete
         float ms = 0.f;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
         c->stats.device_ms += ms;
@@ -716,7 +716,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             }
             return DFX_OK;
         }
-        HIPCHK(c, hipStreamSynchronize(c->d2h_stream));
+        HIPCHK(c, dfx_stream_wait(c, c->d2h_stream));
         if (bounce || out.jpeg) {
             rc = scatter(last);
             if (rc != DFX_OK)
@@ -827,13 +827,15 @@ int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));
         for (auto &e : c->ev_h2d)
-            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&e, dfx_event_flags(c, false)));
         for (auto &e : c->ev_compute)
-            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&e, dfx_event_flags(c, false)));
         for (auto &e : c->ev_d2h)
-            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreate(&c->ev_t0));
-        HIPCHK(c, hipEventCreate(&c->ev_t1));
+            HIPCHK(c, hipEventCreateWithFlags(&e, dfx_event_flags(c, false)));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_t0, dfx_event_flags(c, true)));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_t1, dfx_event_flags(c, true)));
+        if (c->prm.blocking_sync)
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_block, dfx_event_flags(c, false)));
         if (algo == DFX_ALGO_TVL1)
             c->engine = dfx_make_tvl1_engine(c);
         else if (algo == DFX_ALGO_FARN)
@@ -1309,6 +1311,8 @@ void dfx_destroy(dfx_handle h) {
         (void)hipStreamDestroy(h->copy_stream);
     if (h->d2h_stream)
         (void)hipStreamDestroy(h->d2h_stream);
+    if (h->ev_block)
+        (void)hipEventDestroy(h->ev_block);
     if (h->ev_t0)
         (void)hipEventDestroy(h->ev_t0);
     if (h->ev_t1)

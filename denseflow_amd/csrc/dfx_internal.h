@@ -71,6 +71,7 @@ struct dfx_context {
     hipStream_t copy_stream = nullptr; // host -> device copies of the host-pointer entry points
     hipStream_t d2h_stream = nullptr;  // device -> host copies: uploads of the next batch / FlowBuffer overlap them
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_block = nullptr; // dfx_params.blocking_sync: the event dfx_stream_wait sleeps on
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};     // frames of batch i are in staging set i&1
     hipEvent_t ev_compute[2] = {nullptr, nullptr}; // flows of batch i are in staging set i&1
     hipEvent_t ev_d2h[2] = {nullptr, nullptr};     // flow staging set i&1 has been copied out
@@ -155,6 +156,20 @@ int dfx_finish_tails(dfx_context *c, unsigned long long up_to, int parity, bool 
             return DFX_ERR_HIP;                                                                                 \
         }                                                                                                       \
     } while (0)
+
+// Event flags of the hot path's events: with dfx_params.blocking_sync a hipEventSynchronize sleeps instead of spinning.
+inline unsigned dfx_event_flags(const dfx_context *c, bool timing) {
+    return (timing ? 0u : (unsigned)hipEventDisableTiming) | (c->prm.blocking_sync ? (unsigned)hipEventBlockingSync : 0u);
+}
+// hipStreamSynchronize spins (the device flags are whatever the process set up before this library saw the device);
+// with blocking_sync the wait goes through a blocking event instead.  One waiter per context at a time (the calling
+// thread of the calc / submit entry points).
+inline hipError_t dfx_stream_wait(dfx_context *c, hipStream_t s) {
+    if (!c->prm.blocking_sync || !c->ev_block)
+        return hipStreamSynchronize(s);
+    const hipError_t e = hipEventRecord(c->ev_block, s);
+    return e != hipSuccess ? e : hipEventSynchronize(c->ev_block);
+}
 
 inline int dfx_fail(dfx_context *c, int code, const std::string &msg) {
     if (c)

@@ -238,8 +238,8 @@ int FarnebackEngine::create() {
     HIPCHK(c, hipMalloc(&d_pairs, sizeof(PairDesc) * B));
     HIPCHK(c, hipHostMalloc(&h_pairs_pinned, sizeof(PairDesc) * B, hipHostMallocDefault));
     for (auto &e : ev_it) {
-        HIPCHK(c, hipEventCreate(&e[0]));
-        HIPCHK(c, hipEventCreate(&e[1]));
+        HIPCHK(c, hipEventCreateWithFlags(&e[0], dfx_event_flags(c, true)));
+        HIPCHK(c, hipEventCreateWithFlags(&e[1], dfx_event_flags(c, true)));
     }
     return ensure_frame_slots(B + 1);
 }
@@ -300,30 +300,45 @@ int FarnebackEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, lo
     x.slot_stride = slot_stride;
     x.pairs = d_pairs;
     x.n_pairs = nb;
+    // M recomputed inside the iteration kernel (round 4) unless the window is not the reference's 13 or a cross-check
+    // form is asked for; the M-in-HBM kernels need the first updateMatrices launch of every level
+    const bool fused = p.impl == 0 && half == 6 && !(p.variant & DFX_VAR_FARN_M_IN_HBM);
+    int set = (nlev - 1) & 1; // flow set the level's iterations start from (the previous level ended in the other one)
     for (int k = nlev - 1; k >= 0; --k) {
         x.L = lv[k].g;
-        const int cur = k & 1; // flow of level k lives in set k&1; level k+1 is in the other set
         if (k == nlev - 1) {
-            farn_launch_init_flow(c->stream, x, cur, 0, 0, 0, 0.f, 0.f, 0.f, 1);
+            farn_launch_init_flow(c->stream, x, set, 0, 0, 0, 0.f, 0.f, 0.f, 1);
         } else {
             const FarnLevelGeom &P = lv[k + 1].g;
             const float ifx = (float)(1.0 / ((double)x.L.w / (double)P.w));
             const float ify = (float)(1.0 / ((double)x.L.h / (double)P.h));
-            farn_launch_init_flow(c->stream, x, cur, P.w, P.h, P.pitch, ifx, ify, up, 0);
+            farn_launch_init_flow(c->stream, x, set, P.w, P.h, P.pitch, ifx, ify, up, 0); // reads set ^ 1
         }
-        farn_launch_update_matrices(c->stream, x, cur, 0);
-        int m_src = 0;
-        HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
-        for (int it = 0; it < p.farn_num_iters; ++it) {
-            const int dm = it < p.farn_num_iters - 1;
-            farn_launch_iteration(c->stream, x, cur, m_src, half, box_inv, dm, c->prm.impl);
-            if (dm)
-                m_src ^= 1;
+        if (fused) {
+            HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
+            for (int it = 0; it < p.farn_num_iters; ++it) {
+                farn_launch_iter_fused(c->stream, x, set, set ^ 1, box_inv);
+                set ^= 1;
+            }
+            HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));
+            c->stats.kernel_launches += 1 + p.farn_num_iters;
+        } else {
+            farn_launch_update_matrices(c->stream, x, set, 0);
+            int m_src = 0;
+            HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
+            for (int it = 0; it < p.farn_num_iters; ++it) {
+                const int dm = it < p.farn_num_iters - 1;
+                farn_launch_iteration(c->stream, x, set, m_src, half, box_inv, dm, c->prm.impl);
+                if (dm)
+                    m_src ^= 1;
+            }
+            HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));
+            c->stats.kernel_launches += 2 + p.farn_num_iters;
         }
-        HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));
-        c->stats.kernel_launches += 2 + p.farn_num_iters;
+        set ^= 1; // the next (finer) level is initialised into the other set, from the one this level ended in
     }
-    farn_launch_merge(c->stream, x, 0, d_out, out_stride);
+    set ^= 1;     // the set level 0 ended in
+    farn_launch_merge(c->stream, x, set, d_out, out_stride);
     c->stats.kernel_launches += 1;
     return DFX_OK;
 }

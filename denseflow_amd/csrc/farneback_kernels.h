@@ -5,9 +5,9 @@
 //   frame slot f : for every pyramid level k the polynomial expansion R of that frame, 5 planes
 //                  (B.5) of pitch_k x h_k, at element offset r_off[k]; computed once per frame and
 //                  used as R1 of pair i and R0 of pair i+step
-//   pair slot b  : FARN_PL_COUNT planes sized for level 0: flow x/y (two sets: the level being
-//                  solved and the previous level it is up-sampled from) and M (two sets of 5 planes,
-//                  ping-pong: the fused iteration reads a 6-pixel halo of the old M while writing the new)
+//   pair slot b  : FARN_PL_COUNT planes sized for level 0: flow x/y (two sets: the iterations ping-pong
+//                  between them, and a level is up-sampled from the set the previous level ended in) and,
+//                  for the M-in-HBM kernels only (impl = 1, DFX_VAR_FARN_M_IN_HBM), M (two sets of 5 planes)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -52,7 +52,8 @@ void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_
 void farn_launch_polyexp(hipStream_t s, const float *pyr, long long pyr_frame_stride, int n_frames,
                          const int *frame_slots, float *frame_R, long long frame_stride, FarnLevelGeom L,
                          FarnPolyConsts pc, int rows_per_workgroup);
-// the defaults of the two frame-preparation switches (the engine reads DFX_FARN_SKIP0 / DFX_FARN_POLYROWS once at creation)
+// the defaults of the two frame-preparation switches (the engine overrides them from dfx_params.variant:
+// DFX_VAR_FARN_EVAL_ZERO_TAPS, DFX_VAR_FARN_POLY_ONE_ROW)
 int farn_skip_zero_weights_default();
 int farn_polyexp_rows_default();
 // flow(level k) = resize(flow(level k+1)) * (1/pyrScale), or zero at the coarsest level
@@ -62,4 +63,6 @@ void farn_launch_update_matrices(hipStream_t s, const FarnPairCtx &c, int flow_s
 // boxFilter5 + updateFlow (+ updateMatrices) in one launch (B.8, B.9, B.7)
 void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, int m_src, int half, float box_inv,
                            int do_matrices, int impl);
+// the iteration with M recomputed on the halo tile (winSize 13 only): reads flow set flow_in, writes flow set flow_out
+void farn_launch_iter_fused(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv);
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride);

@@ -674,6 +674,402 @@ __global__ __launch_bounds__(256) void k_farn_iteration_t(FarnPairCtx c, int flo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the iteration with M never in HBM (VERDICT r3 "Next round" item 4).
+//
+// k_farn_iteration_t reads the five M planes of the previous launch with a 6-pixel halo and writes the next five: 40 of
+// SURVEY.md section 8d's 136 algorithmic B/px per iteration and, measured at the bench's batch of 129 pairs, 90 B/px of
+// real HBM traffic at ~5 TB/s — it is HBM-bound.  But B.7's updateMatrices is a POINTWISE function of (flow, R0, gathered
+// R1) at a pixel, so the M of every pixel of the 76 x 44 halo tile can be recomputed here from the previous launch's FLOW
+// (8 B/px instead of 20, and nothing written back):
+//     phase 1  updateMatrices on tile + halo                      -> M in LDS (68 KB), planes interleaved in pairs
+//     phase 2  vertical 13-sums, in place                         (16-row column strips held in registers)
+//     phase 3  horizontal 13-sums + the 2x2 solve (B.8, B.9)      -> flow_out
+// The flow ping-pongs between its two plane sets (a workgroup reads its neighbours' previous flow while they write the
+// next one); the first k_farn_update_matrices launch of a level disappears.
+//
+// The price is VALU work (updateMatrices and its gather run on 1.63 x the pixels), so the arithmetic is written for
+// v_pk_*_f32 (two IEEE operations per lane and issue slot, each half rounded on its own — bit-identical to the scalar
+// form): LDS holds (M0, M2) and (M3, M4) as float2 planes and M1 alone, which makes every box-filter addition of phases
+// 2 / 3 a packed addition of two planes (M1: of two columns in phase 2), and updateMatrices itself pairs its products.
+// Every sum keeps upstream's order (centre + (l1 + r1) + (l2 + r2) ...).  Same operations on the same inputs in the same
+// order => bit-identical flows: tests/test_farneback_gpu.py holds this kernel, the M-in-HBM kernel
+// (dfx_params.variant & DFX_VAR_FARN_M_IN_HBM), the simple kernels (impl = 1) and the oracle to each other.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// Loads at a uniform base + a 32-bit BYTE offset: the form the compiler turns into `global_load ... v_off, s[base]`
+// (one VGPR of address per load instead of a 64-bit add per load; an element offset would have to be widened before the
+// * 4 and falls back to 64-bit VALU address arithmetic).
+__device__ __forceinline__ float farn_ld1(const float *base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ f2 farn_ld2u(const float *base, unsigned byte_off) { // 4-byte aligned pair
+    const float2_a4 t = *reinterpret_cast<const float2_a4 *>(reinterpret_cast<const char *>(base) + byte_off);
+    f2 r;
+    r.x = t[0], r.y = t[1];
+    return r;
+}
+__device__ __forceinline__ f2 farn_ld2(const float *base, unsigned byte_off) { // 8-byte aligned pair
+    const float2_a8 t = *reinterpret_cast<const float2_a8 *>(reinterpret_cast<const char *>(base) + byte_off);
+    f2 r;
+    r.x = t[0], r.y = t[1];
+    return r;
+}
+__device__ __forceinline__ f2 farn_f2(float a, float b) {
+    f2 r;
+    r.x = a, r.y = b;
+    return r;
+}
+
+// c_farn_border[min(d, 5)] without the table (a per-lane constant-memory load each): d >= 0
+__device__ __forceinline__ float farn_border_w(int d) { return d < 2 ? 0.14f : (d < 5 ? 0.4472f : 1.f); }
+
+// B.7 for the halo tile, update_matrices_px operation for operation, split in three so that the two pixels of a work item
+// can share their R1 loads: the sample position, the bilinear sample of one plane, and everything after the samples.
+struct FarnGeo {
+    int x1, y1;   // top-left tap
+    f2 w0, w1;    // (a00, a01), (a10, a11)
+    bool valid;   // all four taps inside the image (B.7's test)
+};
+__device__ __forceinline__ FarnGeo farn_geo(int x, int y, float dx, float dy, int w, int h) {
+    FarnGeo g;
+    float fx = (float)x + dx;
+    float fy = (float)y + dy;
+    g.x1 = (int)floorf(fx);
+    g.y1 = (int)floorf(fy);
+    fx -= (float)g.x1;
+    fy -= (float)g.y1;
+    g.valid = (unsigned)g.x1 < (unsigned)(w - 1) && (unsigned)g.y1 < (unsigned)(h - 1); // x1, y1 >= 0, x1 < w-1, y1 < h-1
+    const f2 wx = farn_f2(1.f - fx, fx);
+    g.w0 = wx * (1.f - fy);
+    g.w1 = wx * fy;
+    return g;
+}
+// ((a00 * t00 + a01 * t01) + a10 * t10) + a11 * t11 with the four products as two packed multiplications
+__device__ __forceinline__ float farn_bilinear(const FarnGeo &g, f2 row0, f2 row1) {
+    const f2 t0 = g.w0 * row0, t1 = g.w1 * row1;
+    return ((t0.x + t0.y) + t1.x) + t1.y;
+}
+// Everything after the samples (v[] is ignored where !valid).  Out: m02 = (M0, M2), m34 = (M3, M4), m1 = M1.
+__device__ __forceinline__ void farn_um_finish(bool valid, const float (&v)[5], const float (&r0)[5], float dx, float dy,
+                                               int x, int y, int w, int h, bool unit_scale, f2 &m02, f2 &m34, float &m1) {
+    const float r2s = valid ? v[0] : 0.f, r3s = valid ? v[1] : 0.f;
+    const f2 r45v = (farn_f2(r0[2], r0[3]) + farn_f2(v[2], v[3])) * 0.5f;
+    f2 r45 = farn_f2(valid ? r45v.x : r0[2], valid ? r45v.y : r0[3]);
+    float r6 = valid ? (r0[4] + v[4]) * 0.25f : r0[4] * 0.5f;
+    f2 r23 = (farn_f2(r0[0], r0[1]) - farn_f2(r2s, r3s)) * 0.5f;
+    r23 = r23 + (farn_f2(r45.x, r6) * dy + farn_f2(r6, r45.y) * dx); // r2 += r4*dy + r6*dx ; r3 += r6*dy + r5*dx
+    if (!unit_scale) {
+        float scale = farn_border_w(min(x, 5)) * farn_border_w(min(y, 5));
+        scale = scale * farn_border_w(min(w - x - 1, 5));
+        scale = scale * farn_border_w(min(h - y - 1, 5));
+        r23 = r23 * scale;
+        r45 = r45 * scale;
+        r6 *= scale;
+    }
+    const float r66 = r6 * r6;
+    m02 = r45 * r45 + farn_f2(r66, r66);                           // r4*r4 + r6*r6 ; r5*r5 + r6*r6
+    m1 = (r45.x + r45.y) * r6;                                     // (r4 + r5) * r6
+    m34 = farn_f2(r45.x, r6) * r23.x + farn_f2(r6, r45.y) * r23.y; // r4*r2 + r6*r3 ; r6*r2 + r5*r3
+}
+
+typedef float float4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f4 farn_ld4u(const float *base, unsigned byte_off) { // 4-byte aligned quad
+    const float4_a4 t = *reinterpret_cast<const float4_a4 *>(reinterpret_cast<const char *>(base) + byte_off);
+    f4 r;
+    r.x = t[0], r.y = t[1], r.z = t[2], r.w = t[3];
+    return r;
+}
+
+// The five bilinear samples of R1 for the TWO horizontally adjacent pixels of a work item.  The kernel is bound by the
+// texture-address unit (TA busy 76 % of the time with one 8-byte gather per tap row: profiles/round4/farn_iter/), and the
+// second pixel's taps are, wherever the flow is smooth, the first pixel's shifted by one column: then ONE 16-byte load per
+// row and plane (columns x1 .. x1 + 3) serves both pixels — half the gather instructions.  `joint` = both pixels valid, same
+// tap row, second tap column 0 .. 2 right of the first, window inside the row; other lanes take the per-pixel gathers.
+// Same values into the same arithmetic either way.
+__device__ __forceinline__ void farn_sample_pair(const float *__restrict__ R1, unsigned ps, int w, int pitch,
+                                                 const FarnGeo &ga, const FarnGeo &gb, float (&va)[5], float (&vb)[5]) {
+    const int off = gb.x1 - ga.x1;
+    const bool joint = ga.valid && gb.valid && gb.y1 == ga.y1 && (unsigned)off <= 2u && ga.x1 + 3 <= w - 1;
+    const unsigned qa = (unsigned)(ga.y1 * pitch + ga.x1) * 4u, qa1 = qa + (unsigned)pitch * 4u;
+    if (__all(joint && off == 1)) { // the whole wave: static taps
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const float *Rp = R1 + p * ps;
+            const f4 t0 = farn_ld4u(Rp, qa), t1 = farn_ld4u(Rp, qa1);
+            va[p] = farn_bilinear(ga, farn_f2(t0.x, t0.y), farn_f2(t1.x, t1.y));
+            vb[p] = farn_bilinear(gb, farn_f2(t0.y, t0.z), farn_f2(t1.y, t1.z));
+        }
+        return;
+    }
+    if (joint) {
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const float *Rp = R1 + p * ps;
+            const f4 t0 = farn_ld4u(Rp, qa), t1 = farn_ld4u(Rp, qa1);
+            va[p] = farn_bilinear(ga, farn_f2(t0.x, t0.y), farn_f2(t1.x, t1.y));
+            const f2 b0 = off == 0 ? farn_f2(t0.x, t0.y) : off == 1 ? farn_f2(t0.y, t0.z) : farn_f2(t0.z, t0.w);
+            const f2 b1 = off == 0 ? farn_f2(t1.x, t1.y) : off == 1 ? farn_f2(t1.y, t1.z) : farn_f2(t1.z, t1.w);
+            vb[p] = farn_bilinear(gb, b0, b1);
+        }
+    } else {
+        if (ga.valid) {
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const float *Rp = R1 + p * ps;
+                va[p] = farn_bilinear(ga, farn_ld2u(Rp, qa), farn_ld2u(Rp, qa1));
+            }
+        }
+        if (gb.valid) {
+            const unsigned qb = (unsigned)(gb.y1 * pitch + gb.x1) * 4u, qb1 = qb + (unsigned)pitch * 4u;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const float *Rp = R1 + p * ps;
+                vb[p] = farn_bilinear(gb, farn_ld2u(Rp, qb), farn_ld2u(Rp, qb1));
+            }
+        }
+    }
+}
+
+// Measurement builds only (scripts/build_variant.sh -DFARN_PHASE_MASK=n): bit 0 = phase 1, bit 1 = phase 2, bit 2 = phase 3.
+// A phase that is switched off is replaced by the cheapest code that keeps the others alive; results are then garbage.
+#ifndef FARN_PHASE_MASK
+#define FARN_PHASE_MASK 7
+#endif
+template <int HALF>
+__global__ __launch_bounds__(512) void k_farn_iter_fused(FarnPairCtx c, int flow_in, int flow_out, float box_inv) {
+    constexpr int NT = 512, TW = 64, TH = 32, IW = TW + 2 * HALF, IH = TH + 2 * HALF;
+    static_assert(HALF == 6 && IW == 76 && IH == 44, "strip / bank layout worked out for a 76 x 44 halo tile");
+    // float2 rows of 78 (156 words = 28 mod 64): the lanes of a 16-byte read group of phase 3 walk down the rows and land
+    // on 16 distinct 4-bank slots; the single-float plane's 76 words (= 12 mod 64) do the same
+    constexpr int PA = IW + 2;
+    __shared__ __attribute__((aligned(16))) f2 A[IH][PA];    // (M0, M2)
+    __shared__ __attribute__((aligned(16))) f2 B[IH][PA];    // (M3, M4)
+    __shared__ __attribute__((aligned(16))) float C[IH][IW]; // M1
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const DfxBlockXY blk = dfx_block_xy(); // the 76 x 44 halo tiles of neighbours overlap: one L2 serves the re-reads
+    const int x0 = blk.x * TW, y0 = blk.y * TH;
+    const int w = c.L.w, h = c.L.h, pitch = c.L.pitch;
+    const unsigned ps = (unsigned)pitch * (unsigned)h;
+    const PairDesc pd = c.pairs[b];
+    const float *R0 = c.frame_R + (long long)pd.frame_a * c.frame_stride + c.L.r_off;
+    const float *R1 = c.frame_R + (long long)pd.frame_b * c.frame_stride + c.L.r_off;
+    const float *FXi = farn_plane(c, b, FARN_PL_FX0 + 2 * flow_in), *FYi = farn_plane(c, b, FARN_PL_FY0 + 2 * flow_in);
+
+    // ---- phase 1: M of the halo tile, a pair of columns per work item, at the clamped coordinates the box filter's
+    // replicate border reads.  x0 - HALF is even and the pitch a multiple of 64, so where the 76 columns need no clamping
+    // (every tile but the first / last of a row) a pair's flow and R0 values are 8-byte loads.  The flows of all of a
+    // thread's items are fetched first: the gather addresses depend on them, and one exposed memory latency per item
+    // instead of two is what this phase's time is made of.
+    constexpr int NE2 = IW / 2 * IH;          // 1672 column pairs
+    constexpr int NR1 = (NE2 + NT - 1) / NT;  // 4 items per thread (the last one for 136 threads only)
+    const bool xin = x0 >= HALF && x0 + TW + HALF <= w;
+    // border attenuation is exactly 1 for every pixel of the halo tile: x, y, w - 1 - x, h - 1 - y all >= 5
+    const bool unit_scale = x0 - HALF >= 5 && x0 + TW + HALF - 1 <= w - 6 && y0 - HALF >= 5 && y0 + TH + HALF - 1 <= h - 6;
+    f2 fdx[NR1], fdy[NR1];
+#pragma unroll
+    for (int r = 0; r < NR1; ++r) {
+        const int e = min(tid + r * NT, NE2 - 1);
+        const int ty = e / (IW / 2), tx = 2 * (e - ty * (IW / 2));
+        const int gy = min(max(y0 - HALF + ty, 0), h - 1);
+        const int gxa = x0 - HALF + tx;
+        if (xin) {
+            const unsigned o = (unsigned)(gy * pitch + gxa) * 4u;
+            fdx[r] = farn_ld2(FXi, o);
+            fdy[r] = farn_ld2(FYi, o);
+        } else {
+            const unsigned o0 = (unsigned)(gy * pitch + min(max(gxa, 0), w - 1)) * 4u;
+            const unsigned o1 = (unsigned)(gy * pitch + min(max(gxa + 1, 0), w - 1)) * 4u;
+            fdx[r] = farn_f2(farn_ld1(FXi, o0), farn_ld1(FXi, o1));
+            fdy[r] = farn_f2(farn_ld1(FYi, o0), farn_ld1(FYi, o1));
+        }
+    }
+#if !(FARN_PHASE_MASK & 1)
+    for (int e = tid; e < NE2; e += NT) {
+        const int ty = e / (IW / 2), tx = 2 * (e - ty * (IW / 2));
+        f4 a;
+        a.x = fdx[0].x, a.y = fdy[0].y, a.z = (float)e, a.w = 1.f;
+        *reinterpret_cast<f4 *>(&A[ty][tx]) = a;
+        *reinterpret_cast<f4 *>(&B[ty][tx]) = a;
+        *reinterpret_cast<f2 *>(&C[ty][tx]) = farn_f2(a.x, a.z);
+    }
+#else
+#pragma unroll
+    for (int r = 0; r < NR1; ++r) {
+        const int e = tid + r * NT;
+        if (e < NE2) {
+            const int ty = e / (IW / 2), tx = 2 * (e - ty * (IW / 2));
+            const int gy = min(max(y0 - HALF + ty, 0), h - 1);
+            const int gxa = x0 - HALF + tx;
+            int gx[2];
+            float r0[2][5];
+            if (xin) {
+                gx[0] = gxa, gx[1] = gxa + 1;
+                const unsigned o = (unsigned)(gy * pitch + gxa) * 4u;
+#pragma unroll
+                for (int p = 0; p < 5; ++p) {
+                    const f2 t = farn_ld2(R0 + p * ps, o);
+                    r0[0][p] = t.x, r0[1][p] = t.y;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    gx[j] = min(max(gxa + j, 0), w - 1);
+                    const unsigned o = (unsigned)(gy * pitch + gx[j]) * 4u;
+#pragma unroll
+                    for (int p = 0; p < 5; ++p)
+                        r0[j][p] = farn_ld1(R0 + p * ps, o);
+                }
+            }
+            f2 m02[2], m34[2];
+            float m1[2];
+            const FarnGeo ga = farn_geo(gx[0], gy, fdx[r].x, fdy[r].x, w, h);
+            const FarnGeo gb = farn_geo(gx[1], gy, fdx[r].y, fdy[r].y, w, h);
+            float va[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, vb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            farn_sample_pair(R1, ps, w, pitch, ga, gb, va, vb);
+            farn_um_finish(ga.valid, va, r0[0], fdx[r].x, fdy[r].x, gx[0], gy, w, h, unit_scale, m02[0], m34[0], m1[0]);
+            farn_um_finish(gb.valid, vb, r0[1], fdx[r].y, fdy[r].y, gx[1], gy, w, h, unit_scale, m02[1], m34[1], m1[1]);
+            f4 a, bb;
+            a.x = m02[0].x, a.y = m02[0].y, a.z = m02[1].x, a.w = m02[1].y;
+            bb.x = m34[0].x, bb.y = m34[0].y, bb.z = m34[1].x, bb.w = m34[1].y;
+            *reinterpret_cast<f4 *>(&A[ty][tx]) = a;
+            *reinterpret_cast<f4 *>(&B[ty][tx]) = bb;
+            *reinterpret_cast<f2 *>(&C[ty][tx]) = farn_f2(m1[0], m1[1]);
+        }
+    }
+#endif
+    __syncthreads();
+
+    // ---- phase 2: vertical sums, in place.  Work item = 16 output rows of one float2 column: 28 tile rows into
+    // registers, 16 packed sums in upstream's order (centre + (up_1 + down_1) + (up_2 + down_2) ...), written back to tile
+    // rows 16 s .. 16 s + 15 once every item has read its inputs (the two strips overlap in what they read).
+    // Items: A and B, 2 strips x 76 columns each, 96 lanes per (plane pair, strip) so that a 32-lane read group never
+    // straddles two of them (conflict-free 8-byte reads); the single plane C as 2 strips x 38 column PAIRS in the last
+    // 128 lanes.  380 of 512 lanes work.
+    f2 *vcol = nullptr;   // first input / output of this lane's column, or nullptr
+    int vstride = 0;      // float2 elements between rows
+    if (tid < 4 * 96) {
+        const int g = tid / 96, col = tid - g * 96;
+        if (col < IW) {
+            vcol = ((g & 2) ? &B[0][0] : &A[0][0]) + (g & 1) * 16 * PA + col;
+            vstride = PA;
+        }
+    } else {
+        const int g = (tid - 4 * 96) >> 6, cp = (tid - 4 * 96) & 63;
+        if (cp < IW / 2) {
+            vcol = reinterpret_cast<f2 *>(&C[0][0]) + (g * 16) * (IW / 2) + cp;
+            vstride = IW / 2;
+        }
+    }
+    f2 vsum[16];
+    if (vcol && (FARN_PHASE_MASK & 2)) {
+        f2 v[16 + 2 * HALF];
+#pragma unroll
+        for (int j = 0; j < 16 + 2 * HALF; ++j)
+            v[j] = vcol[j * vstride];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            f2 acc = v[i + HALF];
+#pragma unroll
+            for (int j = 1; j <= HALF; ++j)
+                acc = acc + (v[i + HALF - j] + v[i + HALF + j]);
+            vsum[i] = acc;
+        }
+    }
+    __syncthreads();
+    if (vcol && (FARN_PHASE_MASK & 2)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            vcol[i * vstride] = vsum[i];
+    }
+    __syncthreads();
+#if !(FARN_PHASE_MASK & 4)
+    if (A[tid & 31][tid >> 5].x == 123456.789f) // keeps the LDS contents alive; never true
+        farn_plane(c, b, FARN_PL_FX0 + 2 * flow_out)[tid] = B[0][0].x + C[0][0];
+    return;
+#endif
+
+    // ---- phase 3: horizontal sums for 4 consecutive pixels of one row (16-byte LDS reads), the 2x2 solve, the new flow.
+    const int row = tid & 31, cs = (tid >> 5) * 4;
+    f2 s02[4], s34[4];
+    float s1[4];
+    {
+        f2 v[4 + 2 * HALF];
+        const f4 *src = reinterpret_cast<const f4 *>(&A[row][cs]);
+#pragma unroll
+        for (int q = 0; q < (4 + 2 * HALF) / 2; ++q) {
+            const f4 t = src[q];
+            v[2 * q] = farn_f2(t.x, t.y), v[2 * q + 1] = farn_f2(t.z, t.w);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f2 acc = v[i + HALF];
+#pragma unroll
+            for (int k = 1; k <= HALF; ++k)
+                acc = acc + (v[i + HALF - k] + v[i + HALF + k]);
+            s02[i] = acc * box_inv;
+        }
+    }
+    {
+        f2 v[4 + 2 * HALF];
+        const f4 *src = reinterpret_cast<const f4 *>(&B[row][cs]);
+#pragma unroll
+        for (int q = 0; q < (4 + 2 * HALF) / 2; ++q) {
+            const f4 t = src[q];
+            v[2 * q] = farn_f2(t.x, t.y), v[2 * q + 1] = farn_f2(t.z, t.w);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f2 acc = v[i + HALF];
+#pragma unroll
+            for (int k = 1; k <= HALF; ++k)
+                acc = acc + (v[i + HALF - k] + v[i + HALF + k]);
+            s34[i] = acc * box_inv;
+        }
+    }
+    {
+        float v[4 + 2 * HALF];
+        const f4 *src = reinterpret_cast<const f4 *>(&C[row][cs]);
+#pragma unroll
+        for (int q = 0; q < (4 + 2 * HALF) / 4; ++q) {
+            const f4 t = src[q];
+            v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float acc = v[i + HALF];
+#pragma unroll
+            for (int k = 1; k <= HALF; ++k)
+                acc = acc + (v[i + HALF - k] + v[i + HALF + k]);
+            s1[i] = acc * box_inv;
+        }
+    }
+    const int x = x0 + cs, y = y0 + row;
+    if (x >= w || y >= h)
+        return;
+    float fxo[4], fyo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float g11 = s02[i].x, g12 = s1[i], g22 = s02[i].y, h1 = s34[i].x, h2 = s34[i].y;
+        const float detInv = 1.f / ((g11 * g22 - g12 * g12) + 1e-3f);
+        fxo[i] = (g11 * h2 - g12 * h1) * detInv;
+        fyo[i] = (g22 * h1 - g12 * h2) * detInv;
+    }
+    float *FXo = farn_plane(c, b, FARN_PL_FX0 + 2 * flow_out) + (unsigned)(y * pitch + x);
+    float *FYo = farn_plane(c, b, FARN_PL_FY0 + 2 * flow_out) + (unsigned)(y * pitch + x);
+    if (x + 3 < w) { // pitch is a multiple of 64 and x of 4: 16-byte stores
+        *reinterpret_cast<float4 *>(FXo) = make_float4(fxo[0], fxo[1], fxo[2], fxo[3]);
+        *reinterpret_cast<float4 *>(FYo) = make_float4(fyo[0], fyo[1], fyo[2], fyo[3]);
+    } else {
+        for (int i = 0; i < 4 && x + i < w; ++i) {
+            FXo[i] = fxo[i];
+            FYo[i] = fyo[i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_farn_merge(FarnPairCtx c, int flow_set, float *out, long long out_stride) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -758,6 +1154,11 @@ void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, in
     }
     const dim3 grid((c.L.w + 63) / 64, (c.L.h + 15) / 16, c.n_pairs);
     hipLaunchKernelGGL(k_farn_iteration, grid, dim3(256), 0, s, c, flow_set, m_src, half, box_inv, do_matrices);
+}
+
+void farn_launch_iter_fused(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv) {
+    const dim3 grid((c.L.w + 63) / 64, (c.L.h + 31) / 32, c.n_pairs);
+    hipLaunchKernelGGL(k_farn_iter_fused<6>, grid, dim3(512), 0, s, c, flow_in, flow_out, box_inv);
 }
 
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride) {

@@ -183,11 +183,11 @@ int Tvl1Engine::create() {
     HIPCHK(c, hipHostMalloc(&h_done_flag, 64, hipHostMallocMapped));
     *h_done_flag = 0;
     HIPCHK(c, hipHostGetDevicePointer((void **)&d_done_flag, h_done_flag, 0));
-    HIPCHK(c, hipEventCreateWithFlags(&ev_group[0], hipEventDisableTiming));
-    HIPCHK(c, hipEventCreateWithFlags(&ev_group[1], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&ev_group[0], dfx_event_flags(c, false)));
+    HIPCHK(c, hipEventCreateWithFlags(&ev_group[1], dfx_event_flags(c, false)));
     for (auto &e : ev_lvl) {
-        HIPCHK(c, hipEventCreate(&e[0]));
-        HIPCHK(c, hipEventCreate(&e[1]));
+        HIPCHK(c, hipEventCreateWithFlags(&e[0], dfx_event_flags(c, true)));
+        HIPCHK(c, hipEventCreateWithFlags(&e[1], dfx_event_flags(c, true)));
     }
     return ensure_frame_slots(B + 1);
 }
@@ -311,7 +311,7 @@ int Tvl1Engine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
                         break;
                 }
                 if (step_id > hard_limit + 2 * G) {
-                    HIPCHK(c, hipStreamSynchronize(c->stream));
+                    HIPCHK(c, dfx_stream_wait(c, c->stream));
                     if (*(volatile int *)h_done_flag == x.done_token)
                         break;
                     return dfx_fail(c, DFX_ERR_HIP, "TVL1 level did not terminate within its step bound");

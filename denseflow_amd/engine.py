@@ -62,12 +62,13 @@ class DfxParams(C.Structure):
         ("tvl1_math", C.c_int),
         ("variant", C.c_int),
         ("step_group", C.c_int),
+        ("blocking_sync", C.c_int),
     ]
 
 
 # dfx_params.variant bits (include/dfx.h): cross-check / measurement forms of the tuned kernels, all bit-identical
 VAR_TVL1_CLASSIC_GEOM, VAR_TVL1_WARP_IN_STEP = 0x01, 0x02
-VAR_FARN_EVAL_ZERO_TAPS, VAR_FARN_POLY_ONE_ROW = 0x04, 0x08
+VAR_FARN_EVAL_ZERO_TAPS, VAR_FARN_POLY_ONE_ROW, VAR_FARN_M_IN_HBM = 0x04, 0x08, 0x10
 
 
 class DfxStats(C.Structure):

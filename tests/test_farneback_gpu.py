@@ -123,3 +123,30 @@ def test_frame_preparation_variants_do_not_change_a_bit(dfx, oracle, w, h, seed)
             out = eng.calc_optflows(frames, 1)
         for i, (a, b) in enumerate(zip(out, base)):
             assert np.array_equal(a, b), f"variant={variant}: pair {i} changed"
+
+
+@pytest.mark.parametrize("w,h,seed,iters", [(256, 128, 3, 10), (640, 360, 4, 10), (97, 61, 9, 10), (33, 40, 2, 10),
+                                            (130, 97, 5, 3), (64, 64, 8, 1), (1920, 1080, 2, 10), (1000, 77, 6, 10)])
+def test_iteration_kernel_forms_do_not_change_a_bit(dfx, oracle, w, h, seed, iters):
+    """Round 4: the default iteration kernel recomputes updateMatrices on its 76 x 44 halo tile from the previous launch's
+    flow (M never in HBM; the flow ping-pongs between its two plane sets, so an odd iteration count ends in the other set).
+    It must produce the bits of the M-in-HBM kernel of rounds 1-3 (DFX_VAR_FARN_M_IN_HBM), of the simple kernels (impl = 1)
+    and of the oracle — for even and odd iteration counts, tiles that touch every border, and batches."""
+    from denseflow_amd import engine as E
+
+    frames = SynthClip(w, h, seed).frames(4)
+    kw = dict(max_batch=2, farn_num_iters=iters)
+    with dfx.FlowEngine(w, h, "farn", **kw) as eng:
+        out = eng.calc_optflows(frames, 1)
+    with dfx.FlowEngine(w, h, "farn", variant=E.VAR_FARN_M_IN_HBM, **kw) as eng:
+        in_hbm = eng.calc_optflows(frames, 1)
+    for i, (a, b) in enumerate(zip(out, in_hbm)):
+        assert np.array_equal(a, b), f"pair {i}: recomputed-M kernel differs from the M-in-HBM kernel"
+    if w * h <= 640 * 360:
+        with dfx.FlowEngine(w, h, "farn", impl=1, **kw) as eng:
+            simple = eng.calc_optflows(frames, 1)
+        p = oracle.farneback_default_params()
+        p.num_iters = iters
+        for i in range(3):
+            assert np.array_equal(out[i], simple[i]), f"pair {i}: differs from impl = 1"
+            assert np.array_equal(out[i], oracle.farneback_calc(frames[i], frames[i + 1], p)), f"pair {i}: differs from the oracle"
