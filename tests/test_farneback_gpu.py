@@ -150,3 +150,24 @@ def test_iteration_kernel_forms_do_not_change_a_bit(dfx, oracle, w, h, seed, ite
         for i in range(3):
             assert np.array_equal(out[i], simple[i]), f"pair {i}: differs from impl = 1"
             assert np.array_equal(out[i], oracle.farneback_calc(frames[i], frames[i + 1], p)), f"pair {i}: differs from the oracle"
+
+
+@pytest.mark.parametrize("w,h", [(256, 128), (640, 360), (200, 300)])
+def test_iteration_kernel_on_unrelated_frames(dfx, oracle, w, h):
+    """Frames that have nothing to do with each other (two different textures, and a texture against noise): the flow is
+    large and erratic, taps leave the image, and the R1 footprint of a 76 x 44 tile no longer fits the LDS staging buffer of
+    the default iteration kernel — its gather-from-memory path and its invalid-tap handling run.  Same bits as the
+    M-in-HBM kernel, the simple kernels and the oracle."""
+    from denseflow_amd import engine as E
+
+    rng = np.random.default_rng(w * 1000 + h)
+    noise = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    frames = [SynthClip(w, h, 31).frame(0), SynthClip(w, h, 32).frame(5), noise, SynthClip(w, h, 31).frame(40)]
+    with dfx.FlowEngine(w, h, "farn", max_batch=2) as eng:
+        out = eng.calc_optflows(frames, 1)
+    with dfx.FlowEngine(w, h, "farn", max_batch=2, variant=E.VAR_FARN_M_IN_HBM) as eng:
+        in_hbm = eng.calc_optflows(frames, 1)
+    assert max(float(np.abs(f).max()) for f in out) > 8.0, "the case is meant to produce flows that vary by many pixels"
+    for i in range(3):
+        assert np.array_equal(out[i], in_hbm[i]), f"pair {i}: differs from the M-in-HBM kernel"
+        assert np.array_equal(out[i], oracle.farneback_calc(frames[i], frames[i + 1])), f"pair {i}: differs from the oracle"
