@@ -823,6 +823,13 @@ int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height
 
     auto init = [&]() -> int {
         HIPCHK(c, hipSetDevice(device));
+        if (c->prm.blocking_sync) {
+            // The runtime's waits spin unless the DEVICE is set to blocking scheduling: hipEventBlockingSync alone left the
+            // waiting thread at 100 % CPU (profiles/round4/pmc/blocking_sync_ab.txt).  A process that has already fixed the
+            // device's flags (an error here) keeps its own choice.
+            (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+            (void)hipGetLastError();
+        }
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking));

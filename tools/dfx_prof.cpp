@@ -7,6 +7,8 @@
 // FlowBuffer, one JSON line with the rate and the engine's own statistics.  Measurement tooling, not part of the product.
 //
 //   dfx_prof <algo tvl1|farn|brox> <W> <H> <frames.raw> <n_frames> <step> <passes> [max_batch] [variant] [tvl1_math] [block]
+#include <sys/resource.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -66,10 +68,17 @@ int main(int argc, char **argv) {
     };
     pass(); // warm-up: allocations, first-touch
     dfx_reset_stats(h);
+    auto cpu_s = []() { // user + system CPU seconds of this process (all threads)
+        rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        return ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);
+    };
+    const double c0 = cpu_s();
     const auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < passes; ++i)
         pass();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const double cpu = cpu_s() - c0;
     dfx_stats st;
     dfx_get_stats(h, &st);
     // a checksum of the last flow so that two builds can be compared for identical output
@@ -87,13 +96,15 @@ int main(int argc, char **argv) {
     std::printf("{\"algo\":\"%s\",\"W\":%d,\"H\":%d,\"frames\":%d,\"step\":%d,\"passes\":%d,\"pairs_per_s\":%.3f,"
                 "\"batch\":%d,\"step_launches\":%llu,\"avg_launch_us\":%.3f,\"device_ms_per_pair\":%.5f,"
                 "\"step_algorithmic_bytes_per_launch\":%.1f,\"kernel_launches\":%llu,\"noop_steps\":%llu,"
-                "\"tvl1_mean_iters\":%.3f,\"last_flow_checksum\":\"%016llx\"}\n",
+                "\"tvl1_mean_iters\":%.3f,\"cpu_ms_per_pair\":%.4f,\"cpu_busy_fraction\":%.3f,\"blocking_sync\":%d,"
+                "\"last_flow_checksum\":\"%016llx\"}\n",
                 argv[1], W, H, N, step, passes, passes * (double)M / dt, st.batch, (unsigned long long)st.step_launches,
                 st.step_launches ? st.step_ms * 1e3 / (double)st.step_launches : 0.0,
                 st.pairs ? st.device_ms / (double)st.pairs : 0.0,
                 st.step_launches ? st.step_algorithmic_bytes / (double)st.step_launches : 0.0,
                 (unsigned long long)st.kernel_launches, (unsigned long long)st.noop_steps,
-                st.pairs ? (double)st.tvl1_total_iters / (double)st.pairs : 0.0, sum);
+                st.pairs ? (double)st.tvl1_total_iters / (double)st.pairs : 0.0,
+                passes * M > 0 ? cpu * 1e3 / (passes * (double)M) : 0.0, cpu / dt, prm.blocking_sync, sum);
     dfx_device_free(h, d_frames);
     dfx_device_free(h, d_flows);
     dfx_destroy(h);
