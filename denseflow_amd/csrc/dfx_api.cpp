@@ -5,6 +5,7 @@
 // :282-370 — pair selection :315-316, per-pair upload/calc/download :317-339, M = max(N-|step|,0)
 // flows per FlowBuffer :307-308.
 #include <algorithm>
+#include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -412,7 +413,8 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 return trc;
             if (jb[k].overflow)
                 return dfx_fail(c, DFX_ERR_UNSUPPORTED,
-                                "JPEG: the batch does not compress below 4 bits per pixel (use the 8-bit plane output)");
+                                "JPEG: the batch does not compress below 4 bits per pixel, or one of its planes may not fit "
+                                "jpg_capacity (use the 8-bit plane output and encode on the host)");
             if (jb[k].total > 0)
                 HIPCHK(c, hipMemcpyAsync(c->jpeg.h_stream[q], c->jpeg.d_stream[q], (size_t)jb[k].total,
                                          hipMemcpyDeviceToHost, c->d2h_stream));
@@ -626,6 +628,12 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             for (int j = 0; j < 2 * p.nb; ++j) {
                 jb[k].bits.push_back(hi[2 + 2 * j]);
                 jb[k].base.push_back(hi[2 + 2 * j + 1]);
+                // A single plane that cannot fit the caller's buffer even in the worst case of byte stuffing (every
+                // byte 0xFF: twice the segment) is reported HERE, synchronously and with the status that means "encode
+                // this FlowBuffer on the host" — not as DFX_ERR_INVALID from a deferred tail, which the host shell can
+                // only treat as fatal.  Past this check jpeg_assemble cannot run out of room.
+                if (c->jpeg.header.size() + 2 * (size_t)((hi[2 + 2 * j] >> 3) + 1) + 2 > out.jpg_capacity)
+                    jb[k].overflow = 1;
             }
         }
     }
@@ -861,10 +869,29 @@ int dfx_create(dfx_handle *out, int device, dfx_algo algo, int width, int height
     return DFX_OK;
 }
 
+namespace {
+// dfx_next_segments applies to the NEXT calc / submit call only, whether that call succeeds or not (include/dfx.h).  The
+// list is consumed inside calc_batch_body, which a call rejected by its wrapper's argument checks never reaches: every
+// public entry point holds one of these, so a rejected call cannot leave the list armed for an unrelated later one.
+struct SegmentsScope {
+    dfx_context *c;
+    explicit SegmentsScope(dfx_context *ctx) : c(ctx) {}
+    ~SegmentsScope() {
+        if (c)
+            c->next_segments.clear();
+    }
+    void hand_over() { c = nullptr; } // another entry point takes over (dfx_calc -> dfx_calc_batch)
+};
+// |step| for the wrappers' early size computations; INT_MIN (whose negation is not an int) saturates, and the body
+// rejects it with every other out-of-range step.
+inline int abs_step(int step) { return step == INT_MIN ? INT_MAX : std::abs(step); }
+} // namespace
+
 int dfx_calc(dfx_handle h, const uint8_t *a, size_t a_pitch, const uint8_t *b, size_t b_pitch, float *flow_uv,
              size_t out_pitch) {
     if (!h)
         return DFX_ERR_INVALID;
+    SegmentsScope seg_scope(h);
     if (!a || !b || !flow_uv)
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frame or flow pointer");
     const size_t rb = h->in_row_bytes();
@@ -879,10 +906,12 @@ int dfx_calc(dfx_handle h, const uint8_t *a, size_t a_pitch, const uint8_t *b, s
         }
         const uint8_t *fr[2] = {ta.data(), tb.data()};
         float *fl[1] = {flow_uv};
+        seg_scope.hand_over();
         return dfx_calc_batch(h, fr, rb, 2, 1, fl, out_pitch);
     }
     const uint8_t *fr[2] = {a, b};
     float *fl[1] = {flow_uv};
+    seg_scope.hand_over();
     return dfx_calc_batch(h, fr, a_pitch, 2, 1, fl, out_pitch);
 }
 
@@ -890,7 +919,8 @@ int dfx_calc_batch(dfx_handle h, const uint8_t *const *frames, size_t frame_pitc
                    float *const *flows_uv, size_t out_pitch) {
     if (!h)
         return DFX_ERR_INVALID;
-    const int M = std::max(n_frames - std::abs(step), 0);
+    SegmentsScope seg_scope(h);
+    const int M = std::max(n_frames - abs_step(step), 0);
     if (M > 0 && (!frames || !flows_uv))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or flows array");
     if (M > 0 && (frame_pitch < h->in_row_bytes() || out_pitch < (size_t)h->W * 8))
@@ -905,7 +935,8 @@ int dfx_calc_batch_device(dfx_handle h, const uint8_t *d_frames, size_t pitch, s
                           int step, float *d_flows, size_t flow_stride_floats) {
     if (!h)
         return DFX_ERR_INVALID;
-    const int M = std::max(n_frames - std::abs(step), 0);
+    SegmentsScope seg_scope(h);
+    const int M = std::max(n_frames - abs_step(step), 0);
     if (M > 0 && (!d_frames || !d_flows))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL device frames or flows");
     if (M > 0 && (pitch < h->in_row_bytes() || frame_stride < pitch * (size_t)h->in_h() ||
@@ -922,7 +953,8 @@ int dfx_calc_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame_p
                       size_t img_pitch) {
     if (!h)
         return DFX_ERR_INVALID;
-    const int M = std::max(n_frames - std::abs(step), 0);
+    SegmentsScope seg_scope(h);
+    const int M = std::max(n_frames - abs_step(step), 0);
     if (M > 0 && (!frames || !img_x || !img_y))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or image plane array");
     if (M > 0 && (frame_pitch < h->in_row_bytes() || img_pitch < (size_t)h->W))
@@ -941,9 +973,10 @@ int dfx_submit_batch(dfx_handle h, const uint8_t *const *frames, size_t frame_pi
                      float *const *flows_uv, size_t out_pitch, uint64_t *ticket) {
     if (!h)
         return DFX_ERR_INVALID;
+    SegmentsScope seg_scope(h);
     if (!ticket)
         return dfx_fail(h, DFX_ERR_INVALID, "NULL ticket");
-    const int M = std::max(n_frames - std::abs(step), 0);
+    const int M = std::max(n_frames - abs_step(step), 0);
     if (M > 0 && (!frames || !flows_uv))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or flows array");
     if (M > 0 && (frame_pitch < h->in_row_bytes() || out_pitch < (size_t)h->W * 8))
@@ -962,9 +995,10 @@ int dfx_submit_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame
                         size_t img_pitch, uint64_t *ticket) {
     if (!h)
         return DFX_ERR_INVALID;
+    SegmentsScope seg_scope(h);
     if (!ticket)
         return dfx_fail(h, DFX_ERR_INVALID, "NULL ticket");
-    const int M = std::max(n_frames - std::abs(step), 0);
+    const int M = std::max(n_frames - abs_step(step), 0);
     if (M > 0 && (!frames || !img_x || !img_y))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frames or image plane array");
     if (M > 0 && (frame_pitch < h->in_row_bytes() || img_pitch < (size_t)h->W))
@@ -988,7 +1022,8 @@ int jpeg_entry(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, i
                uint32_t *size_x, uint32_t *size_y, uint64_t *ticket) {
     if (!h)
         return DFX_ERR_INVALID;
-    const int M = std::max(n_frames - std::abs(step), 0);
+    SegmentsScope seg_scope(h);
+    const int M = std::max(n_frames - abs_step(step), 0);
     if (M > 0 && (!frames || !jpg_x || !jpg_y || !size_x || !size_y))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL frames, JPEG buffer or size array");
     if (M > 0 && frame_pitch < h->in_row_bytes())
@@ -1027,8 +1062,10 @@ int dfx_submit_batch_jpeg(dfx_handle h, const uint8_t *const *frames, size_t fra
                           double lower_bound, double upper_bound, int quality, uint8_t *const *jpg_x,
                           uint8_t *const *jpg_y, size_t jpg_capacity, uint32_t *size_x, uint32_t *size_y,
                           uint64_t *ticket) {
-    if (h && !ticket)
+    if (h && !ticket) {
+        h->next_segments.clear();
         return dfx_fail(h, DFX_ERR_INVALID, "NULL ticket");
+    }
     return jpeg_entry(h, frames, frame_pitch, n_frames, step, lower_bound, upper_bound, quality, jpg_x, jpg_y,
                       jpg_capacity, size_x, size_y, ticket);
 }
@@ -1095,8 +1132,8 @@ size_t dfx_jpeg_capacity(dfx_handle h) {
     if (!h)
         return 0;
     // header (623 bytes) + the entropy-coded segment.  A plane whose segment exceeds its pixel count (8 bits per pixel
-    // BEFORE stuffing) is far outside what flow images produce; such a FlowBuffer fails with DFX_ERR_INVALID /
-    // DFX_ERR_UNSUPPORTED and the caller encodes its 8-bit planes (dfx_calc_batch_u8) itself.
+    // BEFORE stuffing) is far outside what flow images produce; such a FlowBuffer fails with DFX_ERR_UNSUPPORTED and the
+    // caller encodes its 8-bit planes (dfx_calc_batch_u8) itself.
     return (size_t)h->W * h->H + 4096;
 }
 
@@ -1127,7 +1164,8 @@ int dfx_calc_batch_u8_device(dfx_handle h, const uint8_t *d_frames, size_t pitch
                              size_t img_pitch, size_t img_stride) {
     if (!h)
         return DFX_ERR_INVALID;
-    const int M = std::max(n_frames - std::abs(step), 0);
+    SegmentsScope seg_scope(h);
+    const int M = std::max(n_frames - abs_step(step), 0);
     if (M > 0 && (!d_frames || !d_img_x || !d_img_y))
         return dfx_fail(h, DFX_ERR_INVALID, "NULL device frames or image planes");
     if (M > 0 && (pitch < h->in_row_bytes() || frame_stride < pitch * (size_t)h->in_h() || img_pitch < (size_t)h->W ||

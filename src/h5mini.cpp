@@ -355,31 +355,61 @@ void append(const std::string &path, const std::vector<FloatDataset> &datasets) 
         if (ix.heap < ix.btree && ix.heap >= hdr_hi && root_end == start)
             start = ix.heap;
     }
-    Writer w{fc.f, path, start};
-    std::unordered_set<std::string> names;
-    for (const Entry &e : ix.entries)
-        names.insert(e.name);
-    std::vector<uint8_t> row;
-    for (const FloatDataset &d : datasets) {
-        if (!names.insert(d.name).second)
-            fail(path, ("dataset exists: " + d.name).c_str());
-        const uint64_t data_addr = w.pos;
-        if (d.pitch_bytes == d.cols * sizeof(float)) {
-            pwrite_exact(fc.f, path, data_addr, d.data, d.rows * d.cols * sizeof(float));
-        } else {
-            for (size_t r = 0; r < d.rows; ++r)
-                pwrite_exact(fc.f, path, data_addr + r * d.cols * sizeof(float),
-                             (const uint8_t *)d.data + r * d.pitch_bytes, d.cols * sizeof(float));
-        }
-        w.pos = (data_addr + d.rows * d.cols * sizeof(float) + 7) & ~7ull;
-        const uint64_t hdr = w.put(dataset_header(d.rows, d.cols, data_addr));
-        ix.entries.push_back(Entry{d.name, hdr});
+    // Every name is checked before the first byte is written (H5LTmake_dataset_float fails on an existing name; a
+    // duplicate found half-way used to leave the old index overwritten: ADVICE r3).
+    {
+        std::unordered_set<std::string> names;
+        for (const Entry &e : ix.entries)
+            names.insert(e.name);
+        for (const FloatDataset &d : datasets)
+            if (!names.insert(d.name).second)
+                fail(path, ("dataset exists: " + d.name).c_str());
     }
-    std::sort(ix.entries.begin(), ix.entries.end(),
-              [](const Entry &a, const Entry &b) { return strcmp(a.name.c_str(), b.name.c_str()) < 0; });
-    uint64_t btree, heap;
-    write_group(w, ix.entries, ix.leaf_k, ix.internal_k, btree, heap);
-    finish(w, ix.root_header, ix.root_msg_data_off, btree, heap);
+    // The append stays recoverable: the bytes of the old index that the new datasets overwrite, and the three words of
+    // the superblock / root header that finish() patches, are kept in memory until the new index is complete; any
+    // failure in between (ENOSPC, a short write) puts them back, so the file is the valid file it was before the call.
+    std::vector<uint8_t> old_tail(start < ix.eof ? (size_t)(ix.eof - start) : 0);
+    if (!old_tail.empty())
+        pread_exact(fc.f, path, start, old_tail.data(), old_tail.size());
+    uint8_t old_msg[16], old_scratch[16], old_eof[8];
+    pread_exact(fc.f, path, ix.root_msg_data_off, old_msg, 16);
+    pread_exact(fc.f, path, 56 + 24, old_scratch, 16);
+    pread_exact(fc.f, path, 40, old_eof, 8);
+    try {
+        Writer w{fc.f, path, start};
+        for (const FloatDataset &d : datasets) {
+            const uint64_t data_addr = w.pos;
+            if (d.pitch_bytes == d.cols * sizeof(float)) {
+                pwrite_exact(fc.f, path, data_addr, d.data, d.rows * d.cols * sizeof(float));
+            } else {
+                for (size_t r = 0; r < d.rows; ++r)
+                    pwrite_exact(fc.f, path, data_addr + r * d.cols * sizeof(float),
+                                 (const uint8_t *)d.data + r * d.pitch_bytes, d.cols * sizeof(float));
+            }
+            w.pos = (data_addr + d.rows * d.cols * sizeof(float) + 7) & ~7ull;
+            const uint64_t hdr = w.put(dataset_header(d.rows, d.cols, data_addr));
+            ix.entries.push_back(Entry{d.name, hdr});
+        }
+        std::sort(ix.entries.begin(), ix.entries.end(),
+                  [](const Entry &a, const Entry &b) { return strcmp(a.name.c_str(), b.name.c_str()) < 0; });
+        uint64_t btree, heap;
+        write_group(w, ix.entries, ix.leaf_k, ix.internal_k, btree, heap);
+        finish(w, ix.root_header, ix.root_msg_data_off, btree, heap);
+    } catch (...) {
+        // best effort, no further throw from here: if the medium is gone nothing can be put back anyway
+        clearerr(fc.f);
+        bool ok = true;
+        auto put_back = [&](uint64_t off, const void *src, size_t n) {
+            ok = ok && fseek(fc.f, (long)off, SEEK_SET) == 0 && fwrite(src, 1, n, fc.f) == n;
+        };
+        if (!old_tail.empty())
+            put_back(start, old_tail.data(), old_tail.size());
+        put_back(ix.root_msg_data_off, old_msg, 16);
+        put_back(56 + 24, old_scratch, 16);
+        put_back(40, old_eof, 8);
+        (void)fflush(fc.f);
+        throw;
+    }
 }
 
 } // namespace h5mini

@@ -5,6 +5,7 @@ a file written by libhdf5's own H5Fcreate can be appended to."""
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -185,3 +186,48 @@ def test_many_flowbuffers_grow_the_file_linearly(h5h, tmp_path):
     growth = np.diff(sizes)
     assert growth.max() <= 2 * (2 * per * (5 * 9 * 4 + 4 + 144 + 24)) + 8 + 512 * 40 + 64  # no term that grows with b
     _check(p, expect)
+
+
+def test_failed_append_leaves_the_file_as_it_was(h5h, tmp_path):
+    """an append that fails part-way must not cost the file its previous contents.  Two ways to fail:
+    a duplicate name that is not the first dataset of the call (every name is now checked before the first write), and a
+    write error in the middle of the call (RLIMIT_FSIZE in a child process: the bytes of the old index that the new
+    datasets had already overwritten are put back)."""
+    p = str(tmp_path / "v.h5")
+    err = C.create_string_buffer(512)
+    assert h5h.h5h_create(p.encode(), err, 512) == 0
+    rng = np.random.default_rng(3)
+    first = rng.standard_normal((2, 5, 7)).astype(np.float32)
+    assert _append(h5h, p, ["a", "b"], first)[0] == 0
+    expect = {"a": first[0], "b": first[1]}
+    before = open(p, "rb").read()
+    rc, msg = _append(h5h, p, ["c", "a"], rng.standard_normal((2, 5, 7)).astype(np.float32))
+    assert rc != 0 and "dataset exists: a" in msg
+    assert open(p, "rb").read() == before  # not a byte was written
+    _check(p, expect)
+
+    # a write error after the old index has been overwritten: the child may grow the file by 4 KB only, the append needs ~1 MB
+    child = f"""
+import ctypes as C, resource, signal, sys
+import numpy as np
+signal.signal(signal.SIGXFSZ, signal.SIG_IGN)
+L = C.CDLL({os.path.join(ROOT, "tests", "_build", "libh5mini_harness.so")!r})
+L.h5h_append.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+n = 4
+a = np.ones((n, 256, 256), np.float32)
+nm = (C.c_char_p * n)(*[b"big%d" % i for i in range(n)])
+err = C.create_string_buffer(512)
+resource.setrlimit(resource.RLIMIT_FSIZE, ({len(before)} + 4096, resource.RLIM_INFINITY))
+rc = L.h5h_append({p!r}.encode(), n, nm, 256, 256, 256, a.ctypes.data, err, 512)
+print(rc, err.value.decode())
+sys.exit(0 if rc != 0 else 3)
+"""
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Failed to save hdf5 file" in r.stdout
+    assert open(p, "rb").read()[:len(before)] == before  # the old index and the patched words are back
+    _check(p, expect)
+    # and the file still takes appends
+    more = rng.standard_normal((1, 5, 7)).astype(np.float32)
+    assert _append(h5h, p, ["c"], more)[0] == 0
+    _check(p, dict(expect, c=more[0]))

@@ -100,14 +100,27 @@ def test_submit_form_and_capacity_error(dfx, harness):
             for i in range(m):
                 assert bx[i][:sx[i]].tobytes() == _host_file(harness, px[i], 95)
                 assert by[i][:sy[i]].tobytes() == _host_file(harness, py[i], 95)
-        # a capacity that cannot hold the file is an error, not a truncated file
+        # a capacity that may not hold a file is an error, not a truncated file — the status that means "encode this
+        # FlowBuffer on the host" (4 = DFX_ERR_UNSUPPORTED), reported by the call itself, also in the submit form (a deferred
+        # tail could only fail the whole run: ADVICE r3)
         small = 700
         bx = [np.zeros(small, np.uint8) for _ in range(m)]
         by = [np.zeros(small, np.uint8) for _ in range(m)]
         sx, sy = (C.c_uint32 * m)(), (C.c_uint32 * m)()
         rc = L.dfx_calc_batch_jpeg(eng._h, fp, w, n, 1, -20.0, 20.0, 95, (C.c_void_p * m)(*[b.ctypes.data for b in bx]),
                                    (C.c_void_p * m)(*[b.ctypes.data for b in by]), small, sx, sy)
-        assert rc == 1 and b"jpg_capacity" in L.dfx_last_error(eng._h)
+        assert rc == 4 and b"jpg_capacity" in L.dfx_last_error(eng._h)
+        t = C.c_uint64(0)
+        rc = L.dfx_submit_batch_jpeg(eng._h, fp, w, n, 1, -20.0, 20.0, 95, (C.c_void_p * m)(*[b.ctypes.data for b in bx]),
+                                     (C.c_void_p * m)(*[b.ctypes.data for b in by]), small, sx, sy, C.byref(t))
+        assert rc == 4 and b"jpg_capacity" in L.dfx_last_error(eng._h)
+        assert L.dfx_wait(eng._h, 0) == 0  # nothing pending, nothing failed later
+        # a rejected call consumes a pending dfx_next_segments declaration (it applies to the NEXT call only)
+        seg = (C.c_int * 2)(3, 2)
+        assert L.dfx_next_segments(eng._h, seg, 2) == 0
+        assert L.dfx_calc_batch_u8(eng._h, fp, w, n, 1, -20.0, 20.0, None, None, w) == 1  # NULL plane arrays: rejected
+        px2, py2 = eng.calc_optflows_u8(frames, 1, 20)  # an unrelated call afterwards pairs as one clip again
+        assert len(px2) == m and all(np.array_equal(a, b) for a, b in zip(px2, px))
 
 
 def test_golden_files(dfx):
