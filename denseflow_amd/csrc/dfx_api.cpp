@@ -185,6 +185,25 @@ int ensure_jpeg(dfx_context *c, int pairs, int quality) {
     return DFX_OK;
 }
 
+// The shared stream buffers (device + page-locked landing buffer, both parities) re-sized to hold `need` bytes: called
+// when the scan pass of a batch has measured more than the 4 bits per pixel ensure_jpeg() provides for (noise, film
+// grain), so that the batch can be coded again from the planes that are still on the device — the flows are not
+// recomputed and the caller does not have to fall back to the host encoder.
+int grow_jpeg_streams(dfx_context *c, unsigned long long need) {
+    auto &j = c->jpeg;
+    (void)dfx_finish_tails(c, 0, -1); // a deferred tail may still be reading a landing buffer
+    HIPCHK(c, hipDeviceSynchronize());
+    const size_t cap = (((size_t)need + (size_t)need / 4 + (64u << 10)) + 255) & ~(size_t)255;
+    for (int p = 0; p < 2; ++p) {
+        dfx_free_dev(j.d_stream[p]);
+        dfx_free_host(j.h_stream[p]);
+        HIPCHK(c, hipMalloc(&j.d_stream[p], cap));
+        HIPCHK(c, hipHostMalloc(&j.h_stream[p], cap, hipHostMallocDefault));
+    }
+    j.capacity = cap;
+    return DFX_OK;
+}
+
 int ensure_bounce(dfx_context *c, size_t in_bytes, size_t out_bytes) {
     if (in_bytes > c->h_in_bytes) {
         (void)dfx_finish_tails(c, 0, -1);
@@ -596,7 +615,7 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             HIPCHK(c, hipGetLastError());
             c->stats.kernel_launches += 1;
         }
-        if (out.jpeg) { // imencode(".jpg") of both planes of every flow, on the device (src/common.cpp:56-57)
+        auto launch_jpeg = [&]() -> int { // imencode(".jpg") of both planes of every flow, on the device (src/common.cpp:56-57)
             JpegCtx jc;
             jc.planes = c->d_img[par(k)];
             jc.plane_stride = (long long)plane;
@@ -609,6 +628,12 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             jpeg_launch_encode(c->stream, jc);
             HIPCHK(c, hipGetLastError());
             c->stats.kernel_launches += 5;
+            return DFX_OK;
+        };
+        if (out.jpeg) {
+            rc = launch_jpeg();
+            if (rc != DFX_OK)
+                return rc;
         }
         HIPCHK(c, hipEventRecord(c->ev_t1, c->stream));
         HIPCHK(c, hipEventRecord(c->ev_compute[par(k)], c->stream));
@@ -624,6 +649,19 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             return rc;
         if (out.jpeg) { // the stream is idle: the totals of this batch are in the mapped block
             const unsigned long long *hi = c->jpeg.h_info[par(k)];
+            if (hi[1] != 0) {
+                // The batch's streams do not fit the shared buffer (sized for 4 bits per pixel): nothing was written, but
+                // the scan pass has measured what they need.  Grow the buffers to that and code the batch again — its
+                // bounded planes are still in staging set par(k), the flows are not recomputed.
+                rc = grow_jpeg_streams(c, hi[0]);
+                if (rc != DFX_OK)
+                    return rc;
+                rc = launch_jpeg();
+                if (rc != DFX_OK)
+                    return rc;
+                HIPCHK(c, hipEventRecord(c->ev_compute[par(k)], c->stream));
+                HIPCHK(c, dfx_stream_wait(c, c->stream));
+            }
             jb[k].total = hi[0], jb[k].overflow = hi[1];
             for (int j = 0; j < 2 * p.nb; ++j) {
                 jb[k].bits.push_back(hi[2 + 2 * j]);
@@ -1112,9 +1150,18 @@ int dfx_encode_jpeg(dfx_handle h, const uint8_t *const *planes, size_t pitch, in
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipStreamSynchronize(h->stream));
         const unsigned long long *hi = h->jpeg.h_info[0];
+        if (hi[1]) { // more than the 4 bits per pixel the shared buffer was sized for: grow it to what the scan pass measured
+            const int grc = grow_jpeg_streams(h, hi[0]);
+            if (grc != DFX_OK)
+                return grc;
+            jc.stream = h->jpeg.d_stream[0], jc.capacity_bytes = h->jpeg.capacity;
+            jpeg_launch_encode(h->stream, jc);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
         if (hi[1])
             return dfx_fail(h, DFX_ERR_UNSUPPORTED,
-                            "JPEG: the planes do not compress below 4 bits per pixel (encode them on the host)");
+                            "JPEG: the planes do not fit the stream buffer (encode them on the host)");
         HIPCHK(h, hipMemcpyAsync(h->jpeg.h_stream[0], h->jpeg.d_stream[0], (size_t)hi[0], hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (int j = 0; j < nc; ++j) {

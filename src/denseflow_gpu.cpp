@@ -466,7 +466,14 @@ void DenseFlow::prepare_engine(const string &algorithm, const Size &sz) {
     if (dfx_)
         dfx_destroy(dfx_);
     dfx_ = nullptr;
-    if (dfx_create(&dfx_, device, algo, sz.width, sz.height, nullptr) != DFX_OK)
+    // The reference's create() defaults, plus one engine knob: the threads that wait for the device (this stage inside
+    // dfx_submit_*, the collector in dfx_wait) sleep instead of spinning — same rate, ~1 CPU per GPU given back to the
+    // loader / encoder threads, which is what bounds the shell on a host with few cores per GPU (DESIGN.md section 6;
+    // DF_SPIN_WAIT=1 restores the spinning waits for A/B runs).
+    dfx_params prm;
+    dfx_default_params(&prm);
+    prm.blocking_sync = std::getenv("DF_SPIN_WAIT") ? 0 : 1;
+    if (dfx_create(&dfx_, device, algo, sz.width, sz.height, &prm) != DFX_OK)
         throw std::runtime_error(dfx_last_error(nullptr));
     dfx_size_ = sz;
     TRACE("calc: engine for %dx%d ready", sz.width, sz.height);

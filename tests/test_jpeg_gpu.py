@@ -61,20 +61,37 @@ def test_files_are_libjpegs_and_the_host_encoders_byte_for_byte(dfx, harness, al
 
 def test_arbitrary_planes_including_stuffing_and_long_zero_runs(dfx, harness):
     """Planes that are NOT flows, pushed through the same kernels (frames whose flow saturates the bound give planes of
-    0 / 255 runs; noise frames give busy spectra): still the host encoder's bytes, or a clean DFX_ERR_UNSUPPORTED when a
-    batch does not compress below 4 bits per pixel."""
+    0 / 255 runs; noise frames give busy spectra): still the host encoder's bytes.  A batch that does not compress below
+    the 4 bits per pixel the stream buffer is first sized for is coded again after the buffer has grown to what the scan
+    pass measured (round 4) — it used to fail with DFX_ERR_UNSUPPORTED and cost the host shell a second flow computation."""
     rng = np.random.default_rng(8)
     w, h = 200, 120
     frames = [rng.integers(0, 256, (h, w)).astype(np.uint8) for _ in range(4)]  # noise: Farneback flows are garbage
     with dfx.FlowEngine(w, h, "farn") as eng:
         px, py = eng.calc_optflows_u8(frames, 1, 0.05)  # tiny bound: almost everything saturates to 0 / 255
-        try:
-            jx, jy = eng.calc_optflows_jpeg(frames, 1, 0.05, 95)
-        except dfx.DfxError as e:
-            assert e.status == 4 and "4 bits per pixel" in str(e)
-            return
+        jx, jy = eng.calc_optflows_jpeg(frames, 1, 0.05, 95)
     for i in range(3):
         assert jx[i] == _host_file(harness, px[i], 95) and jy[i] == _host_file(harness, py[i], 95)
+
+
+def test_incompressible_planes_grow_the_stream_buffer(dfx, harness):
+    """Bounded planes that ARE noise (a wide bound over garbage flows, quality 100): far above 4 bits per pixel.  The device
+    encoder grows its stream buffer from the scan pass's measurement and still writes the host encoder's bytes — for the
+    FlowBuffer entry point (two batches, so the regrown buffers serve both staging parities) and for dfx_encode_jpeg."""
+    rng = np.random.default_rng(11)
+    w, h = 256, 160
+    frames = [rng.integers(0, 256, (h, w)).astype(np.uint8) for _ in range(6)]
+    planes = [rng.integers(0, 256, (h, w)).astype(np.uint8) for _ in range(3)]
+    with dfx.FlowEngine(w, h, "farn", max_batch=3) as eng:
+        px, py = eng.calc_optflows_u8(frames, 1, 40)
+        jx, jy = eng.calc_optflows_jpeg(frames, 1, 40, 100)
+        bpp = 8.0 * sum(len(f) for f in jx + jy) / (len(jx + jy) * w * h)
+        assert bpp > 4.0, f"the case is meant to exceed the first buffer size ({bpp:.2f} bits per pixel)"
+        for i in range(5):
+            assert jx[i] == _host_file(harness, px[i], 100) and jy[i] == _host_file(harness, py[i], 100), i
+    with dfx.FlowEngine(w, h, "farn") as eng:
+        files = eng.encode_jpeg(planes, 100)
+        assert all(f == _host_file(harness, p, 100) for f, p in zip(files, planes))
 
 
 def test_submit_form_and_capacity_error(dfx, harness):
