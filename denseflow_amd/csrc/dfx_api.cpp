@@ -432,8 +432,8 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 return trc;
             if (jb[k].overflow)
                 return dfx_fail(c, DFX_ERR_UNSUPPORTED,
-                                "JPEG: the batch does not compress below 4 bits per pixel, or one of its planes may not fit "
-                                "jpg_capacity (use the 8-bit plane output and encode on the host)");
+                                "JPEG: the batch's streams do not fit the stream buffer (use the 8-bit plane output and encode "
+                                "on the host)");
             if (jb[k].total > 0)
                 HIPCHK(c, hipMemcpyAsync(c->jpeg.h_stream[q], c->jpeg.d_stream[q], (size_t)jb[k].total,
                                          hipMemcpyDeviceToHost, c->d2h_stream));
@@ -493,7 +493,9 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 const size_t n = jpeg_assemble(c->jpeg.header, hb + jb[k].base[j], jb[k].bits[j],
                                                is_y ? out.jpg_y[i] : out.jpg_x[i], out.jpg_capacity);
                 if (n == 0)
-                    return dfx_fail(c, DFX_ERR_INVALID, "JPEG: jpg_capacity is too small for an encoded plane");
+                    return dfx_fail(c, DFX_ERR_UNSUPPORTED,
+                                    "JPEG: jpg_capacity is too small for an encoded plane (encode this FlowBuffer's 8-bit planes "
+                                    "on the host)");
                 (is_y ? out.size_y : out.size_x)[i] = (uint32_t)n;
             }
             return DFX_OK;
@@ -666,12 +668,6 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
             for (int j = 0; j < 2 * p.nb; ++j) {
                 jb[k].bits.push_back(hi[2 + 2 * j]);
                 jb[k].base.push_back(hi[2 + 2 * j + 1]);
-                // A single plane that cannot fit the caller's buffer even in the worst case of byte stuffing (every
-                // byte 0xFF: twice the segment) is reported HERE, synchronously and with the status that means "encode
-                // this FlowBuffer on the host" — not as DFX_ERR_INVALID from a deferred tail, which the host shell can
-                // only treat as fatal.  Past this check jpeg_assemble cannot run out of room.
-                if (c->jpeg.header.size() + 2 * (size_t)((hi[2 + 2 * j] >> 3) + 1) + 2 > out.jpg_capacity)
-                    jb[k].overflow = 1;
             }
         }
     }
@@ -680,7 +676,14 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         rc = download(last);
         if (rc != DFX_OK)
             return rc;
-        if (ticket) {
+        // A plane of the last batch that could exceed jpg_capacity if every byte of it had to be stuffed (above 4 bits per
+        // pixel against dfx_jpeg_capacity: noise) is assembled HERE, synchronously: "does not fit" is then DFX_ERR_UNSUPPORTED
+        // from this call — the status that means "encode this FlowBuffer on the host" — and never an error of a deferred
+        // tail, which the host shell could only treat as fatal.
+        bool may_not_fit = false;
+        for (size_t j = 0; out.jpeg && j < jb[last].bits.size(); ++j)
+            may_not_fit = may_not_fit || c->jpeg.header.size() + 2 * (size_t)((jb[last].bits[j] >> 3) + 1) + 2 > out.jpg_capacity;
+        if (ticket && !may_not_fit) {
             // deferred tail: wait for the last download and hand its rows over on a helper thread, so that the
             // caller can issue the next FlowBuffer now (its uploads run on the other copy stream)
             std::unique_ptr<dfx_context::Tail> t(new dfx_context::Tail());
@@ -1168,7 +1171,7 @@ int dfx_encode_jpeg(dfx_handle h, const uint8_t *const *planes, size_t pitch, in
             const size_t sz = jpeg_assemble(h->jpeg.header, h->jpeg.h_stream[0] + hi[2 + 2 * j + 1], hi[2 + 2 * j], jpg[i0 + j],
                                             jpg_capacity);
             if (sz == 0)
-                return dfx_fail(h, DFX_ERR_INVALID, "JPEG: jpg_capacity is too small for an encoded plane");
+                return dfx_fail(h, DFX_ERR_UNSUPPORTED, "JPEG: jpg_capacity is too small for an encoded plane");
             sizes[i0 + j] = (uint32_t)sz;
         }
     }
