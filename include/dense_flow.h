@@ -147,6 +147,7 @@ class DenseFlow {
     // Short FlowBuffers of one geometry (a list of small clips, BASELINE configs[3]) that are already waiting are joined
     // into ONE library call (dfx_next_segments): the same flows, fuller device batches.  DF_NO_JOIN=1 disables it.
     bool join_short_ = true;
+    bool blocking_waits_ = false; // sleep, not spin, while waiting for the device (set when several pipelines share the host)
     void submit_group(vector<FlowBuffer> &group, const string &algorithm, int step, bool verbose);
     void collect_flows();
     void enqueue_pending(std::unique_ptr<PendingFlows> p);
@@ -176,6 +177,7 @@ class DenseFlow {
         shard_rank = rank;
         shard_world = world;
     }
+    void set_blocking_waits(bool on) { blocking_waits_ = on; }
     // flows [begin, end) of a clip of n_frames frames that shard `rank` of `world` computes (contiguous, balanced)
     static void shard_range(int n_frames, int step, int rank, int world, int &begin, int &end);
     void extract_frames_only(bool use_frames, bool verbose);

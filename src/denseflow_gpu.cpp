@@ -466,13 +466,15 @@ void DenseFlow::prepare_engine(const string &algorithm, const Size &sz) {
     if (dfx_)
         dfx_destroy(dfx_);
     dfx_ = nullptr;
-    // The reference's create() defaults, plus one engine knob: the threads that wait for the device (this stage inside
-    // dfx_submit_*, the collector in dfx_wait) sleep instead of spinning — same rate, ~1 CPU per GPU given back to the
-    // loader / encoder threads, which is what bounds the shell on a host with few cores per GPU (DESIGN.md section 6;
-    // DF_SPIN_WAIT=1 restores the spinning waits for A/B runs).
+    // The reference's create() defaults, plus one engine knob: with several pipelines on one host (-g: one per GPU) the
+    // threads that wait for the device — this stage inside dfx_submit_*, the collector in dfx_wait — sleep instead of
+    // spinning: 1.6 instead of 2.5 (Farneback) / 4.1 (TVL1) CPU-ms per 1080p pair, CPUs the loader / encoder threads of
+    // eight pipelines need on a 16-CPU allowance.  A single pipeline keeps the spinning waits: blocking costs Farneback
+    // 15 % of its end-to-end rate (wake-up latency per FlowBuffer), TVL1 nothing (profiles/round4/e2e/).
+    // DF_BLOCKING_WAIT=1 / DF_SPIN_WAIT=1 force either (A/B runs).
     dfx_params prm;
     dfx_default_params(&prm);
-    prm.blocking_sync = std::getenv("DF_SPIN_WAIT") ? 0 : 1;
+    prm.blocking_sync = std::getenv("DF_SPIN_WAIT") ? 0 : (std::getenv("DF_BLOCKING_WAIT") ? 1 : (blocking_waits_ ? 1 : 0));
     if (dfx_create(&dfx_, device, algo, sz.width, sz.height, &prm) != DFX_OK)
         throw std::runtime_error(dfx_last_error(nullptr));
     dfx_size_ = sz;
@@ -935,6 +937,7 @@ void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_di
                                            is_record && !split, save_type, devices[g]));
         if (split)
             workers.back()->set_shard((int)g, (int)G);
+        workers.back()->set_blocking_waits(G > 1);
     }
     const double start_t = CurrentSeconds();
     vector<std::exception_ptr> errs(G);
