@@ -317,7 +317,7 @@ int FarnebackEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, lo
         if (fused) {
             HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
             for (int it = 0; it < p.farn_num_iters; ++it) {
-                farn_launch_iter_fused(c->stream, x, set, set ^ 1, box_inv);
+                farn_launch_iter_stream(c->stream, x, set, set ^ 1, box_inv);
                 set ^= 1;
             }
             HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));

@@ -63,6 +63,7 @@ void farn_launch_update_matrices(hipStream_t s, const FarnPairCtx &c, int flow_s
 // boxFilter5 + updateFlow (+ updateMatrices) in one launch (B.8, B.9, B.7)
 void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, int m_src, int half, float box_inv,
                            int do_matrices, int impl);
-// the iteration with M recomputed on the halo tile (winSize 13 only): reads flow set flow_in, writes flow set flow_out
-void farn_launch_iter_fused(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv);
+// the iteration with M recomputed where the box filter needs it (winSize 13 only): reads flow set flow_in, writes flow
+// set flow_out; a stream down 64-column strips with a ring of 18 M rows in LDS (round 4's default)
+void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv);
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride);

@@ -17,6 +17,7 @@
 
 #include <type_traits>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "dfx_device.h"
@@ -675,23 +676,21 @@ __global__ __launch_bounds__(256) void k_farn_iteration_t(FarnPairCtx c, int flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// Round 4: the iteration with M never in HBM (VERDICT r3 "Next round" item 4).
+// Round 4: the iteration with M never in HBM (VERDICT r3 "Next round" item 4) — k_farn_iter_stream below, and the
+// device functions it is made of.
 //
 // k_farn_iteration_t reads the five M planes of the previous launch with a 6-pixel halo and writes the next five: 40 of
 // SURVEY.md section 8d's 136 algorithmic B/px per iteration and, measured at the bench's batch of 129 pairs, 90 B/px of
 // real HBM traffic at ~5 TB/s — it is HBM-bound.  But B.7's updateMatrices is a POINTWISE function of (flow, R0, gathered
-// R1) at a pixel, so the M of every pixel of the 76 x 44 halo tile can be recomputed here from the previous launch's FLOW
-// (8 B/px instead of 20, and nothing written back):
-//     phase 1  updateMatrices on tile + halo                      -> M in LDS (68 KB), planes interleaved in pairs
-//     phase 2  vertical 13-sums, in place                         (16-row column strips held in registers)
-//     phase 3  horizontal 13-sums + the 2x2 solve (B.8, B.9)      -> flow_out
-// The flow ping-pongs between its two plane sets (a workgroup reads its neighbours' previous flow while they write the
-// next one); the first k_farn_update_matrices launch of a level disappears.
+// R1) at a pixel, so M can be recomputed where the box filter needs it from the previous launch's FLOW (8 B/px instead
+// of 20, and nothing written back).  The flow then ping-pongs between its two plane sets (a workgroup reads its
+// neighbours' previous flow while they write the next one) and the first k_farn_update_matrices launch of a level
+// disappears.
 //
-// The price is VALU work (updateMatrices and its gather run on 1.63 x the pixels), so the arithmetic is written for
-// v_pk_*_f32 (two IEEE operations per lane and issue slot, each half rounded on its own — bit-identical to the scalar
-// form): LDS holds (M0, M2) and (M3, M4) as float2 planes and M1 alone, which makes every box-filter addition of phases
-// 2 / 3 a packed addition of two planes (M1: of two columns in phase 2), and updateMatrices itself pairs its products.
+// The price is VALU and gather work on the halo, so the arithmetic is written for v_pk_*_f32 (two IEEE operations per
+// lane and issue slot, each half rounded on its own — bit-identical to the scalar form; packed f32 issues at the scalar
+// rate on gfx950): LDS holds (M0, M2) and (M3, M4) as float2 planes and M1 alone, which makes every box-filter addition a
+// packed addition of two planes (M1: of two columns in the vertical pass), and updateMatrices itself pairs its products.
 // Every sum keeps upstream's order (centre + (l1 + r1) + (l2 + r2) ...).  Same operations on the same inputs in the same
 // order => bit-identical flows: tests/test_farneback_gpu.py holds this kernel, the M-in-HBM kernel
 // (dfx_params.variant & DFX_VAR_FARN_M_IN_HBM), the simple kernels (impl = 1) and the oracle to each other.
@@ -832,241 +831,278 @@ __device__ __forceinline__ void farn_sample_pair(const float *__restrict__ R1, u
     }
 }
 
-// Measurement builds only (scripts/build_variant.sh -DFARN_PHASE_MASK=n): bit 0 = phase 1, bit 1 = phase 2, bit 2 = phase 3.
-// A phase that is switched off is replaced by the cheapest code that keeps the others alive; results are then garbage.
-#ifndef FARN_PHASE_MASK
-#define FARN_PHASE_MASK 7
+// ------------------------------------------------------------------------------------------------
+// The iteration as a STREAM down a column strip.  A workgroup (4 waves) owns 64 output columns of a segment of rows and
+// walks down it 6 rows at a time with a ring of 18 M rows in LDS (27 KB):
+//     step:  updateMatrices for the 6 rows entering the window (76 columns: halo factor 1.19)   -> ring
+//            vertical 13-sums of the 6 output rows, one column per lane, written over the 6 rows leaving the window
+//            horizontal 13-sums + the 2x2 solve for 6 x 64 pixels                               -> flow_out
+// (The first form of this round recomputed M on 64 x 32 tiles with a 6-pixel halo — 1.63 x the pixels, 68 KB of LDS, two
+// workgroups per CU whose gather and summing phases did not overlap: 711 + 323 = 1027 us per launch,
+// profiles/round4/farn_iter/.  The stream reads every input row once per strip and measures 975 us.)
+#ifndef FARN_STREAM_WPS
+#define FARN_STREAM_WPS 3
+#endif
+#ifndef FARN_STREAM_MASK
+#define FARN_STREAM_MASK 3 // measurement builds: bit 0 = updateMatrices, bit 1 = sums + solve
 #endif
 template <int HALF>
-__global__ __launch_bounds__(512) void k_farn_iter_fused(FarnPairCtx c, int flow_in, int flow_out, float box_inv) {
-    constexpr int NT = 512, TW = 64, TH = 32, IW = TW + 2 * HALF, IH = TH + 2 * HALF;
-    static_assert(HALF == 6 && IW == 76 && IH == 44, "strip / bank layout worked out for a 76 x 44 halo tile");
-    // float2 rows of 78 (156 words = 28 mod 64): the lanes of a 16-byte read group of phase 3 walk down the rows and land
-    // on 16 distinct 4-bank slots; the single-float plane's 76 words (= 12 mod 64) do the same
-    constexpr int PA = IW + 2;
-    __shared__ __attribute__((aligned(16))) f2 A[IH][PA];    // (M0, M2)
-    __shared__ __attribute__((aligned(16))) f2 B[IH][PA];    // (M3, M4)
-    __shared__ __attribute__((aligned(16))) float C[IH][IW]; // M1
+__global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnPairCtx c, int flow_in, int flow_out, float box_inv,
+                                                             int seg_rows) {
+    constexpr int TW = 64, IW = TW + 2 * HALF, RB = 6, RING = RB + 2 * HALF, NP = IW / 2; // 38 column pairs per row
+    static_assert(HALF == 6 && RING == 18 && RB * NP <= 256 && RB * (TW / 2) <= 256, "work split worked out for 6-row steps");
+    __shared__ __attribute__((aligned(16))) f2 A[RING][IW];    // (M0, M2)
+    __shared__ __attribute__((aligned(16))) f2 B[RING][IW];    // (M3, M4)
+    __shared__ __attribute__((aligned(16))) float C[RING][IW]; // M1
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
-    const DfxBlockXY blk = dfx_block_xy(); // the 76 x 44 halo tiles of neighbours overlap: one L2 serves the re-reads
-    const int x0 = blk.x * TW, y0 = blk.y * TH;
+    const DfxBlockXY blk = dfx_block_xy();
+    const int x0 = blk.x * TW;
     const int w = c.L.w, h = c.L.h, pitch = c.L.pitch;
+    const int ya = blk.y * seg_rows, yb = min(ya + seg_rows, h);
+    if (ya >= h)
+        return;
     const unsigned ps = (unsigned)pitch * (unsigned)h;
     const PairDesc pd = c.pairs[b];
     const float *R0 = c.frame_R + (long long)pd.frame_a * c.frame_stride + c.L.r_off;
     const float *R1 = c.frame_R + (long long)pd.frame_b * c.frame_stride + c.L.r_off;
     const float *FXi = farn_plane(c, b, FARN_PL_FX0 + 2 * flow_in), *FYi = farn_plane(c, b, FARN_PL_FY0 + 2 * flow_in);
+    float *FXo = farn_plane(c, b, FARN_PL_FX0 + 2 * flow_out), *FYo = farn_plane(c, b, FARN_PL_FY0 + 2 * flow_out);
 
-    // ---- phase 1: M of the halo tile, a pair of columns per work item, at the clamped coordinates the box filter's
-    // replicate border reads.  x0 - HALF is even and the pitch a multiple of 64, so where the 76 columns need no clamping
-    // (every tile but the first / last of a row) a pair's flow and R0 values are 8-byte loads.  The flows of all of a
-    // thread's items are fetched first: the gather addresses depend on them, and one exposed memory latency per item
-    // instead of two is what this phase's time is made of.
-    constexpr int NE2 = IW / 2 * IH;          // 1672 column pairs
-    constexpr int NR1 = (NE2 + NT - 1) / NT;  // 4 items per thread (the last one for 136 threads only)
     const bool xin = x0 >= HALF && x0 + TW + HALF <= w;
-    // border attenuation is exactly 1 for every pixel of the halo tile: x, y, w - 1 - x, h - 1 - y all >= 5
-    const bool unit_scale = x0 - HALF >= 5 && x0 + TW + HALF - 1 <= w - 6 && y0 - HALF >= 5 && y0 + TH + HALF - 1 <= h - 6;
-    f2 fdx[NR1], fdy[NR1];
-#pragma unroll
-    for (int r = 0; r < NR1; ++r) {
-        const int e = min(tid + r * NT, NE2 - 1);
-        const int ty = e / (IW / 2), tx = 2 * (e - ty * (IW / 2));
-        const int gy = min(max(y0 - HALF + ty, 0), h - 1);
-        const int gxa = x0 - HALF + tx;
+    const bool unit_cols = x0 - HALF >= 5 && x0 + TW + HALF - 1 <= w - 6; // border attenuation 1 in x for every column
+    // updateMatrices work item of this thread: row k of the 6 entering rows, column pair pr
+    const bool has_item = tid < RB * NP;
+    const int k1 = has_item ? tid / NP : 0, tx = 2 * ((has_item ? tid : 0) - k1 * NP);
+    const int gxa = x0 - HALF + tx;
+    int gx[2];
+    gx[0] = xin ? gxa : min(max(gxa, 0), w - 1);
+    gx[1] = xin ? gxa + 1 : min(max(gxa + 1, 0), w - 1);
+    auto load_flow = [&](int gy, f2 &dx, f2 &dy) {
         if (xin) {
-            const unsigned o = (unsigned)(gy * pitch + gxa) * 4u;
-            fdx[r] = farn_ld2(FXi, o);
-            fdy[r] = farn_ld2(FYi, o);
+            const unsigned o = (unsigned)(gy * pitch + gx[0]) * 4u;
+            dx = farn_ld2(FXi, o);
+            dy = farn_ld2(FYi, o);
         } else {
-            const unsigned o0 = (unsigned)(gy * pitch + min(max(gxa, 0), w - 1)) * 4u;
-            const unsigned o1 = (unsigned)(gy * pitch + min(max(gxa + 1, 0), w - 1)) * 4u;
-            fdx[r] = farn_f2(farn_ld1(FXi, o0), farn_ld1(FXi, o1));
-            fdy[r] = farn_f2(farn_ld1(FYi, o0), farn_ld1(FYi, o1));
+            const unsigned o0 = (unsigned)(gy * pitch + gx[0]) * 4u, o1 = (unsigned)(gy * pitch + gx[1]) * 4u;
+            dx = farn_f2(farn_ld1(FXi, o0), farn_ld1(FXi, o1));
+            dy = farn_f2(farn_ld1(FYi, o0), farn_ld1(FYi, o1));
         }
-    }
-#if !(FARN_PHASE_MASK & 1)
-    for (int e = tid; e < NE2; e += NT) {
-        const int ty = e / (IW / 2), tx = 2 * (e - ty * (IW / 2));
-        f4 a;
-        a.x = fdx[0].x, a.y = fdy[0].y, a.z = (float)e, a.w = 1.f;
-        *reinterpret_cast<f4 *>(&A[ty][tx]) = a;
-        *reinterpret_cast<f4 *>(&B[ty][tx]) = a;
-        *reinterpret_cast<f2 *>(&C[ty][tx]) = farn_f2(a.x, a.z);
-    }
-#else
+    };
+    // The R0 values and the R1 windows of the item's row, fetched one step AHEAD of their use: with the loads issued at
+    // the start of the step that needs them, a workgroup has nothing in flight while it sums, and the launch runs at the
+    // sum of its memory time and its summing time (measured: 692 us of loads — HBM-bound, 4.9 TB/s — + 393 us of sums
+    // = 1011 us per launch).  Held in registers across the sums of the step before.
+    float pr0[2][5];
+    f4 pw0[5], pw1[5];
+    auto joint_of = [&](const FarnGeo &ga, const FarnGeo &gb) {
+        return ga.valid && gb.valid && gb.y1 == ga.y1 && (unsigned)(gb.x1 - ga.x1) <= 2u && ga.x1 + 3 <= w - 1;
+    };
+    auto issue_row = [&](int gy, f2 dx, f2 dy) {
+        if (xin) {
+            const unsigned o = (unsigned)(gy * pitch + gx[0]) * 4u;
 #pragma unroll
-    for (int r = 0; r < NR1; ++r) {
-        const int e = tid + r * NT;
-        if (e < NE2) {
-            const int ty = e / (IW / 2), tx = 2 * (e - ty * (IW / 2));
-            const int gy = min(max(y0 - HALF + ty, 0), h - 1);
-            const int gxa = x0 - HALF + tx;
-            int gx[2];
-            float r0[2][5];
-            if (xin) {
-                gx[0] = gxa, gx[1] = gxa + 1;
-                const unsigned o = (unsigned)(gy * pitch + gxa) * 4u;
-#pragma unroll
-                for (int p = 0; p < 5; ++p) {
-                    const f2 t = farn_ld2(R0 + p * ps, o);
-                    r0[0][p] = t.x, r0[1][p] = t.y;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    gx[j] = min(max(gxa + j, 0), w - 1);
-                    const unsigned o = (unsigned)(gy * pitch + gx[j]) * 4u;
-#pragma unroll
-                    for (int p = 0; p < 5; ++p)
-                        r0[j][p] = farn_ld1(R0 + p * ps, o);
-                }
+            for (int p = 0; p < 5; ++p) {
+                const f2 t = farn_ld2(R0 + p * ps, o);
+                pr0[0][p] = t.x, pr0[1][p] = t.y;
             }
-            f2 m02[2], m34[2];
-            float m1[2];
-            const FarnGeo ga = farn_geo(gx[0], gy, fdx[r].x, fdy[r].x, w, h);
-            const FarnGeo gb = farn_geo(gx[1], gy, fdx[r].y, fdy[r].y, w, h);
-            float va[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, vb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-            farn_sample_pair(R1, ps, w, pitch, ga, gb, va, vb);
-            farn_um_finish(ga.valid, va, r0[0], fdx[r].x, fdy[r].x, gx[0], gy, w, h, unit_scale, m02[0], m34[0], m1[0]);
-            farn_um_finish(gb.valid, vb, r0[1], fdx[r].y, fdy[r].y, gx[1], gy, w, h, unit_scale, m02[1], m34[1], m1[1]);
-            f4 a, bb;
-            a.x = m02[0].x, a.y = m02[0].y, a.z = m02[1].x, a.w = m02[1].y;
-            bb.x = m34[0].x, bb.y = m34[0].y, bb.z = m34[1].x, bb.w = m34[1].y;
-            *reinterpret_cast<f4 *>(&A[ty][tx]) = a;
-            *reinterpret_cast<f4 *>(&B[ty][tx]) = bb;
-            *reinterpret_cast<f2 *>(&C[ty][tx]) = farn_f2(m1[0], m1[1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned o = (unsigned)(gy * pitch + gx[j]) * 4u;
+#pragma unroll
+                for (int p = 0; p < 5; ++p)
+                    pr0[j][p] = farn_ld1(R0 + p * ps, o);
+            }
         }
-    }
-#endif
-    __syncthreads();
+        const FarnGeo ga = farn_geo(gx[0], gy, dx.x, dy.x, w, h);
+        const FarnGeo gb = farn_geo(gx[1], gy, dx.y, dy.y, w, h);
+        if (joint_of(ga, gb)) { // the 16-byte windows both pixels sample from (farn_sample_pair); other lanes gather late
+            const unsigned qa = (unsigned)(ga.y1 * pitch + ga.x1) * 4u, qa1 = qa + (unsigned)pitch * 4u;
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                pw0[p] = farn_ld4u(R1 + p * ps, qa);
+                pw1[p] = farn_ld4u(R1 + p * ps, qa1);
+            }
+        }
+    };
+    // M of the item's two pixels at image row gy (already clamped) from the prefetched values, into ring slot `slot`
+    auto matrices_row = [&](int gy, f2 dx, f2 dy, int slot) {
+        const bool unit_scale = unit_cols && gy >= 5 && gy <= h - 6;
+        const FarnGeo ga = farn_geo(gx[0], gy, dx.x, dy.x, w, h);
+        const FarnGeo gb = farn_geo(gx[1], gy, dx.y, dy.y, w, h);
+        float va[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, vb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        const int off = gb.x1 - ga.x1;
+        if (joint_of(ga, gb)) {
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const f4 t0 = pw0[p], t1 = pw1[p];
+                va[p] = farn_bilinear(ga, farn_f2(t0.x, t0.y), farn_f2(t1.x, t1.y));
+                const f2 b0 = off == 0 ? farn_f2(t0.x, t0.y) : off == 1 ? farn_f2(t0.y, t0.z) : farn_f2(t0.z, t0.w);
+                const f2 b1 = off == 0 ? farn_f2(t1.x, t1.y) : off == 1 ? farn_f2(t1.y, t1.z) : farn_f2(t1.z, t1.w);
+                vb[p] = farn_bilinear(gb, b0, b1);
+            }
+        } else {
+            farn_sample_pair(R1, ps, w, pitch, ga, gb, va, vb); // takes its per-pixel branch for these lanes
+        }
+        f2 m02[2], m34[2];
+        float m1[2];
+        farn_um_finish(ga.valid, va, pr0[0], dx.x, dy.x, gx[0], gy, w, h, unit_scale, m02[0], m34[0], m1[0]);
+        farn_um_finish(gb.valid, vb, pr0[1], dx.y, dy.y, gx[1], gy, w, h, unit_scale, m02[1], m34[1], m1[1]);
+        f4 a, bb;
+        a.x = m02[0].x, a.y = m02[0].y, a.z = m02[1].x, a.w = m02[1].y;
+        bb.x = m34[0].x, bb.y = m34[0].y, bb.z = m34[1].x, bb.w = m34[1].y;
+        *reinterpret_cast<f4 *>(&A[slot][tx]) = a;
+        *reinterpret_cast<f4 *>(&B[slot][tx]) = bb;
+        *reinterpret_cast<f2 *>(&C[slot][tx]) = farn_f2(m1[0], m1[1]);
+    };
+    // ring row o (counted from image row ya - HALF) lives in slot o % RING and holds M of image row clamp(ya - HALF + o)
+    auto image_row = [&](int o) { return min(max(ya - HALF + o, 0), h - 1); };
 
-    // ---- phase 2: vertical sums, in place.  Work item = 16 output rows of one float2 column: 28 tile rows into
-    // registers, 16 packed sums in upstream's order (centre + (up_1 + down_1) + (up_2 + down_2) ...), written back to tile
-    // rows 16 s .. 16 s + 15 once every item has read its inputs (the two strips overlap in what they read).
-    // Items: A and B, 2 strips x 76 columns each, 96 lanes per (plane pair, strip) so that a 32-lane read group never
-    // straddles two of them (conflict-free 8-byte reads); the single plane C as 2 strips x 38 column PAIRS in the last
-    // 128 lanes.  380 of 512 lanes work.
-    f2 *vcol = nullptr;   // first input / output of this lane's column, or nullptr
-    int vstride = 0;      // float2 elements between rows
-    if (tid < 4 * 96) {
+    // vertical-sum work item of this thread: one float2 column of A or B (96 lanes each so that a 32-lane LDS read group
+    // stays inside one of them), or one column PAIR of the single plane C
+    f2 *vcol = nullptr;
+    int vstride = 0;
+    if (tid < 2 * 96) {
         const int g = tid / 96, col = tid - g * 96;
         if (col < IW) {
-            vcol = ((g & 2) ? &B[0][0] : &A[0][0]) + (g & 1) * 16 * PA + col;
-            vstride = PA;
+            vcol = (g ? &B[0][0] : &A[0][0]) + col;
+            vstride = IW;
         }
-    } else {
-        const int g = (tid - 4 * 96) >> 6, cp = (tid - 4 * 96) & 63;
-        if (cp < IW / 2) {
-            vcol = reinterpret_cast<f2 *>(&C[0][0]) + (g * 16) * (IW / 2) + cp;
-            vstride = IW / 2;
-        }
+    } else if (tid - 2 * 96 < NP) {
+        vcol = reinterpret_cast<f2 *>(&C[0][0]) + (tid - 2 * 96);
+        vstride = NP;
     }
-    f2 vsum[16];
-    if (vcol && (FARN_PHASE_MASK & 2)) {
-        f2 v[16 + 2 * HALF];
-#pragma unroll
-        for (int j = 0; j < 16 + 2 * HALF; ++j)
-            v[j] = vcol[j * vstride];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            f2 acc = v[i + HALF];
-#pragma unroll
-            for (int j = 1; j <= HALF; ++j)
-                acc = acc + (v[i + HALF - j] + v[i + HALF + j]);
-            vsum[i] = acc;
-        }
-    }
-    __syncthreads();
-    if (vcol && (FARN_PHASE_MASK & 2)) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            vcol[i * vstride] = vsum[i];
-    }
-    __syncthreads();
-#if !(FARN_PHASE_MASK & 4)
-    if (A[tid & 31][tid >> 5].x == 123456.789f) // keeps the LDS contents alive; never true
-        farn_plane(c, b, FARN_PL_FX0 + 2 * flow_out)[tid] = B[0][0].x + C[0][0];
-    return;
-#endif
+    // horizontal-sum work item: output row hi of the step, pixels hx, hx + 1 of the strip
+    const bool has_out = tid < RB * (TW / 2);
+    const int hi = tid >> 5, hx = 2 * (tid & 31);
 
-    // ---- phase 3: horizontal sums for 4 consecutive pixels of one row (16-byte LDS reads), the 2x2 solve, the new flow.
-    const int row = tid & 31, cs = (tid >> 5) * 4;
-    f2 s02[4], s34[4];
-    float s1[4];
-    {
-        f2 v[4 + 2 * HALF];
-        const f4 *src = reinterpret_cast<const f4 *>(&A[row][cs]);
-#pragma unroll
-        for (int q = 0; q < (4 + 2 * HALF) / 2; ++q) {
-            const f4 t = src[q];
-            v[2 * q] = farn_f2(t.x, t.y), v[2 * q + 1] = farn_f2(t.z, t.w);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f2 acc = v[i + HALF];
-#pragma unroll
-            for (int k = 1; k <= HALF; ++k)
-                acc = acc + (v[i + HALF - k] + v[i + HALF + k]);
-            s02[i] = acc * box_inv;
-        }
+    // the window's first 12 rows, then the loads of step 0's rows and the flows of step 1's
+    f2 cdx = farn_f2(0.f, 0.f), cdy = cdx; // flow of the row whose loads are in flight
+    f2 ndx = cdx, ndy = cdx;               // flow of the row after that
+    if (has_item) {
+        f2 dx0, dy0, dx1, dy1;
+        load_flow(image_row(k1), dx0, dy0);
+        load_flow(image_row(RB + k1), dx1, dy1);
+        load_flow(image_row(2 * RB + k1), cdx, cdy);
+        issue_row(image_row(k1), dx0, dy0);
+        matrices_row(image_row(k1), dx0, dy0, k1);
+        issue_row(image_row(RB + k1), dx1, dy1);
+        matrices_row(image_row(RB + k1), dx1, dy1, RB + k1);
+        issue_row(image_row(2 * RB + k1), cdx, cdy);
+        load_flow(image_row(3 * RB + k1), ndx, ndy);
     }
-    {
-        f2 v[4 + 2 * HALF];
-        const f4 *src = reinterpret_cast<const f4 *>(&B[row][cs]);
-#pragma unroll
-        for (int q = 0; q < (4 + 2 * HALF) / 2; ++q) {
-            const f4 t = src[q];
-            v[2 * q] = farn_f2(t.x, t.y), v[2 * q + 1] = farn_f2(t.z, t.w);
+    const int n_steps = (yb - ya + RB - 1) / RB;
+    int b0 = 0; // slot of the oldest row of the window = (RB * s) % RING
+    for (int s = 0; s < n_steps; ++s) {
+        // rows 12 + 6 s .. 17 + 6 s enter the window: their loads were issued a step ago
+        if (has_item) {
+            int slot = b0 + 2 * RB + k1;
+            slot -= slot >= RING ? RING : 0;
+#if FARN_STREAM_MASK & 1
+            matrices_row(image_row(2 * RB + RB * s + k1), cdx, cdy, slot);
+            if (s + 1 < n_steps) { // the next step's loads fly while this step sums; the flows of the step after it, too
+                cdx = ndx, cdy = ndy;
+                issue_row(image_row(2 * RB + RB * (s + 1) + k1), cdx, cdy);
+                if (s + 2 < n_steps)
+                    load_flow(image_row(2 * RB + RB * (s + 2) + k1), ndx, ndy);
+            }
+#else
+            A[slot][tx] = cdx, B[slot][tx] = cdy, C[slot][tx] = cdx.x;
+#endif
         }
+        __syncthreads();
+#if !(FARN_STREAM_MASK & 2)
+        if (A[b0][tid & 63].x == 123456.789f)
+            FXo[tid] = B[b0][0].x;
+        b0 += RB;
+        b0 -= b0 >= RING ? RING : 0;
+        continue;
+#endif
+        // vertical sums of the 6 output rows (window rows j = 0 .. 17 -> slots (b0 + j) % 18), this lane's column only:
+        // the sums go where the 6 oldest rows were — nobody else touches this column in this phase
+        if (vcol) {
+            f2 v[RING];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f2 acc = v[i + HALF];
+            for (int j = 0; j < RING; ++j) {
+                int slot = b0 + j;
+                slot -= slot >= RING ? RING : 0;
+                v[j] = vcol[slot * vstride];
+            }
 #pragma unroll
-            for (int k = 1; k <= HALF; ++k)
-                acc = acc + (v[i + HALF - k] + v[i + HALF + k]);
-            s34[i] = acc * box_inv;
+            for (int i = 0; i < RB; ++i) {
+                f2 acc = v[i + HALF];
+#pragma unroll
+                for (int j = 1; j <= HALF; ++j)
+                    acc = acc + (v[i + HALF - j] + v[i + HALF + j]);
+                int slot = b0 + i;
+                slot -= slot >= RING ? RING : 0;
+                vcol[slot * vstride] = acc;
+            }
         }
-    }
-    {
-        float v[4 + 2 * HALF];
-        const f4 *src = reinterpret_cast<const f4 *>(&C[row][cs]);
+        __syncthreads();
+        // horizontal sums + solve for two pixels of one output row
+        const int y = ya + RB * s + hi, x = x0 + hx;
+        if (has_out && y < yb && x < w) {
+            int slot = b0 + hi;
+            slot -= slot >= RING ? RING : 0;
+            f2 s02[2], s34[2];
+            float s1[2];
 #pragma unroll
-        for (int q = 0; q < (4 + 2 * HALF) / 4; ++q) {
-            const f4 t = src[q];
-            v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
+            for (int q = 0; q < 2; ++q) {
+                f2 v[2 + 2 * HALF];
+                const f4 *src = reinterpret_cast<const f4 *>(q ? &B[slot][hx] : &A[slot][hx]);
+#pragma unroll
+                for (int t = 0; t < (2 + 2 * HALF) / 2; ++t) {
+                    const f4 u = src[t];
+                    v[2 * t] = farn_f2(u.x, u.y), v[2 * t + 1] = farn_f2(u.z, u.w);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f2 acc = v[i + HALF];
+#pragma unroll
+                    for (int kk = 1; kk <= HALF; ++kk)
+                        acc = acc + (v[i + HALF - kk] + v[i + HALF + kk]);
+                    (q ? s34 : s02)[i] = acc * box_inv;
+                }
+            }
+            {
+                float v[2 + 2 * HALF];
+                const f2 *src = reinterpret_cast<const f2 *>(&C[slot][hx]);
+#pragma unroll
+                for (int t = 0; t < (2 + 2 * HALF) / 2; ++t) {
+                    const f2 u = src[t];
+                    v[2 * t] = u.x, v[2 * t + 1] = u.y;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float acc = v[i + HALF];
+#pragma unroll
+                    for (int kk = 1; kk <= HALF; ++kk)
+                        acc = acc + (v[i + HALF - kk] + v[i + HALF + kk]);
+                    s1[i] = acc * box_inv;
+                }
+            }
+            float fxo[2], fyo[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float g11 = s02[i].x, g12 = s1[i], g22 = s02[i].y, h1 = s34[i].x, h2 = s34[i].y;
+                const float detInv = 1.f / ((g11 * g22 - g12 * g12) + 1e-3f);
+                fxo[i] = (g11 * h2 - g12 * h1) * detInv;
+                fyo[i] = (g22 * h1 - g12 * h2) * detInv;
+            }
+            const unsigned o = (unsigned)(y * pitch + x);
+            if (x + 1 < w) { // x is even and the pitch a multiple of 64: 8-byte stores
+                *reinterpret_cast<float2 *>(FXo + o) = make_float2(fxo[0], fxo[1]);
+                *reinterpret_cast<float2 *>(FYo + o) = make_float2(fyo[0], fyo[1]);
+            } else {
+                FXo[o] = fxo[0];
+                FYo[o] = fyo[0];
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float acc = v[i + HALF];
-#pragma unroll
-            for (int k = 1; k <= HALF; ++k)
-                acc = acc + (v[i + HALF - k] + v[i + HALF + k]);
-            s1[i] = acc * box_inv;
-        }
-    }
-    const int x = x0 + cs, y = y0 + row;
-    if (x >= w || y >= h)
-        return;
-    float fxo[4], fyo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float g11 = s02[i].x, g12 = s1[i], g22 = s02[i].y, h1 = s34[i].x, h2 = s34[i].y;
-        const float detInv = 1.f / ((g11 * g22 - g12 * g12) + 1e-3f);
-        fxo[i] = (g11 * h2 - g12 * h1) * detInv;
-        fyo[i] = (g22 * h1 - g12 * h2) * detInv;
-    }
-    float *FXo = farn_plane(c, b, FARN_PL_FX0 + 2 * flow_out) + (unsigned)(y * pitch + x);
-    float *FYo = farn_plane(c, b, FARN_PL_FY0 + 2 * flow_out) + (unsigned)(y * pitch + x);
-    if (x + 3 < w) { // pitch is a multiple of 64 and x of 4: 16-byte stores
-        *reinterpret_cast<float4 *>(FXo) = make_float4(fxo[0], fxo[1], fxo[2], fxo[3]);
-        *reinterpret_cast<float4 *>(FYo) = make_float4(fyo[0], fyo[1], fyo[2], fyo[3]);
-    } else {
-        for (int i = 0; i < 4 && x + i < w; ++i) {
-            FXo[i] = fxo[i];
-            FYo[i] = fyo[i];
-        }
+        __syncthreads(); // the 6 slots just read take the next step's new rows
+        b0 += RB;
+        b0 -= b0 >= RING ? RING : 0;
     }
 }
 
@@ -1156,9 +1192,25 @@ void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, in
     hipLaunchKernelGGL(k_farn_iteration, grid, dim3(256), 0, s, c, flow_set, m_src, half, box_inv, do_matrices);
 }
 
-void farn_launch_iter_fused(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv) {
-    const dim3 grid((c.L.w + 63) / 64, (c.L.h + 31) / 32, c.n_pairs);
-    hipLaunchKernelGGL(k_farn_iter_fused<6>, grid, dim3(512), 0, s, c, flow_in, flow_out, box_inv);
+// Rows per segment of the streaming kernel: whole 6-row steps, and enough segments that a launch is many generations of
+// workgroups (256 CUs x 5 slots): a workgroup walks its whole segment, so with few generations the last, nearly empty
+// one costs a full segment time (one segment per column at 1080p: 3.02 generations, measured 1130 us per launch against
+// the tile kernel's 1025).  Each segment pays 12 warm-up rows.
+#ifndef FARN_STREAM_GENERATIONS
+#define FARN_STREAM_GENERATIONS 16
+#endif
+int farn_stream_seg_rows(int w, int h, int n_pairs) {
+    const long long cols = (w + 63) / 64;
+    long long nseg = (FARN_STREAM_GENERATIONS * 1280 + cols * n_pairs - 1) / (cols * n_pairs);
+    nseg = std::max<long long>(1, std::min<long long>(nseg, (h + 47) / 48)); // segments of at least 48 rows
+    const int rows = (int)((h + nseg - 1) / nseg);
+    return (rows + 5) / 6 * 6;
+}
+
+void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv) {
+    const int seg_rows = farn_stream_seg_rows(c.L.w, c.L.h, c.n_pairs);
+    const dim3 grid((c.L.w + 63) / 64, (c.L.h + seg_rows - 1) / seg_rows, c.n_pairs);
+    hipLaunchKernelGGL(k_farn_iter_stream<6>, grid, dim3(256), 0, s, c, flow_in, flow_out, box_inv, seg_rows);
 }
 
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride) {

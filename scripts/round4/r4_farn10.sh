@@ -1,0 +1,14 @@
+#!/bin/bash
+# Round 4: the row-stream Farneback iteration kernel with its loads issued one step ahead: parity, then rates at 3 / 4 / 5 waves per SIMD
+O=gpurun_out/r4_farn10; mkdir -p $O; export TMPDIR=/tmp
+cd /root/repo
+timeout 900 python -m pytest tests/test_farneback_gpu.py -x -q > $O/pytest_farn.log 2>&1; tail -3 $O/pytest_farn.log
+python scripts/make_raw_clip.py 1920 1080 2 130 /tmp/clip1080.raw 2> $O/mk.err || { tail -3 $O/mk.err; exit 1; }
+for m in full wps4 wps5 p1only tile full wps4 wps5 p1only tile; do
+  L=build/variants/$m; v=0
+  [ $m = full ] && L=denseflow_amd/lib
+  [ $m = tile ] && { L=denseflow_amd/lib; v=32; }
+  echo -n "$m " >> $O/rates.txt
+  LD_LIBRARY_PATH=$L ./build/dfx_prof farn 1920 1080 /tmp/clip1080.raw 130 1 3 0 $v 2>> $O/err.log | grep -o '"pairs_per_s":[0-9.]*\|"avg_launch_us":[0-9.]*\|"last_flow_checksum":"[0-9a-f]*"' | paste - - - >> $O/rates.txt
+done
+cat $O/rates.txt

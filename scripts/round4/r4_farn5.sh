@@ -4,7 +4,7 @@ O=gpurun_out/r4_farn5; mkdir -p $O; export TMPDIR=/tmp
 cd /root/repo
 timeout 900 python -m pytest tests/test_farneback_gpu.py -x -q > $O/pytest_farn.log 2>&1; tail -3 $O/pytest_farn.log
 python scripts/make_raw_clip.py 1920 1080 2 130 /tmp/clip1080.raw 2> $O/mk.err || { tail -3 $O/mk.err; exit 1; }
-for v in 0 16 0 16; do ./build/dfx_prof farn 1920 1080 /tmp/clip1080.raw 130 1 3 0 $v >> $O/rates.txt 2>> $O/err.log; done
+for v in 0 32 16 0 32 16; do ./build/dfx_prof farn 1920 1080 /tmp/clip1080.raw 130 1 3 0 $v >> $O/rates.txt 2>> $O/err.log; done
 grep -o '"pairs_per_s":[0-9.]*\|"avg_launch_us":[0-9.]*\|"last_flow_checksum":"[0-9a-f]*"' $O/rates.txt | paste - - -
 R=/root/repo
 run() { n=$1; v=$2; shift 2

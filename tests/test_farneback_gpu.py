@@ -126,12 +126,14 @@ def test_frame_preparation_variants_do_not_change_a_bit(dfx, oracle, w, h, seed)
 
 
 @pytest.mark.parametrize("w,h,seed,iters", [(256, 128, 3, 10), (640, 360, 4, 10), (97, 61, 9, 10), (33, 40, 2, 10),
-                                            (130, 97, 5, 3), (64, 64, 8, 1), (1920, 1080, 2, 10), (1000, 77, 6, 10)])
+                                            (130, 97, 5, 3), (64, 64, 8, 1), (1920, 1080, 2, 10), (1000, 77, 6, 10),
+                                            (70, 500, 12, 4), (129, 49, 14, 10), (65, 43, 15, 2)])
 def test_iteration_kernel_forms_do_not_change_a_bit(dfx, oracle, w, h, seed, iters):
-    """Round 4: the default iteration kernel recomputes updateMatrices on its 76 x 44 halo tile from the previous launch's
-    flow (M never in HBM; the flow ping-pongs between its two plane sets, so an odd iteration count ends in the other set).
-    It must produce the bits of the M-in-HBM kernel of rounds 1-3 (DFX_VAR_FARN_M_IN_HBM), of the simple kernels (impl = 1)
-    and of the oracle — for even and odd iteration counts, tiles that touch every border, and batches."""
+    """Round 4: the default iteration kernel recomputes updateMatrices from the previous launch's flow while it streams down
+    64-column strips (M never in HBM; the flow ping-pongs between its two plane sets, so an odd iteration count ends in the
+    other set).  It must produce the bits of the M-in-HBM kernel of rounds 1-3 (DFX_VAR_FARN_M_IN_HBM), of the simple
+    kernels (impl = 1) and of the oracle — for even and odd iteration counts, strips that touch every border, segments
+    shorter and longer than a 6-row step, and batches."""
     from denseflow_amd import engine as E
 
     frames = SynthClip(w, h, seed).frames(4)
@@ -141,7 +143,7 @@ def test_iteration_kernel_forms_do_not_change_a_bit(dfx, oracle, w, h, seed, ite
     with dfx.FlowEngine(w, h, "farn", variant=E.VAR_FARN_M_IN_HBM, **kw) as eng:
         in_hbm = eng.calc_optflows(frames, 1)
     for i, (a, b) in enumerate(zip(out, in_hbm)):
-        assert np.array_equal(a, b), f"pair {i}: recomputed-M kernel differs from the M-in-HBM kernel"
+        assert np.array_equal(a, b), f"pair {i}: the row-stream kernel differs from the M-in-HBM kernel"
     if w * h <= 640 * 360:
         with dfx.FlowEngine(w, h, "farn", impl=1, **kw) as eng:
             simple = eng.calc_optflows(frames, 1)
@@ -155,8 +157,8 @@ def test_iteration_kernel_forms_do_not_change_a_bit(dfx, oracle, w, h, seed, ite
 @pytest.mark.parametrize("w,h", [(256, 128), (640, 360), (200, 300)])
 def test_iteration_kernel_on_unrelated_frames(dfx, oracle, w, h):
     """Frames that have nothing to do with each other (two different textures, and a texture against noise): the flow is
-    large and erratic, taps leave the image, and the R1 footprint of a 76 x 44 tile no longer fits the LDS staging buffer of
-    the default iteration kernel — its gather-from-memory path and its invalid-tap handling run.  Same bits as the
+    large and erratic, taps leave the image, and neighbouring pixels no longer sample neighbouring taps — the per-pixel
+    gather path (no shared 16-byte window) and the invalid-tap handling of the default iteration kernel run.  Same bits as the
     M-in-HBM kernel, the simple kernels and the oracle."""
     from denseflow_amd import engine as E
 
