@@ -839,9 +839,9 @@ __device__ __forceinline__ void farn_sample_pair(const float *__restrict__ R1, u
 //            horizontal 13-sums + the 2x2 solve for 6 x 64 pixels                               -> flow_out
 // (The first form of this round recomputed M on 64 x 32 tiles with a 6-pixel halo — 1.63 x the pixels, 68 KB of LDS, two
 // workgroups per CU whose gather and summing phases did not overlap: 711 + 323 = 1027 us per launch,
-// profiles/round4/farn_iter/.  The stream reads every input row once per strip and measures 975 us.)
+// profiles/round4/farn_iter/.  The stream reads every input row once per strip and measures 965 us.)
 #ifndef FARN_STREAM_WPS
-#define FARN_STREAM_WPS 3
+#define FARN_STREAM_WPS 4
 #endif
 #ifndef FARN_STREAM_MASK
 #define FARN_STREAM_MASK 3 // measurement builds: bit 0 = updateMatrices, bit 1 = sums + solve
@@ -889,16 +889,13 @@ __global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnP
             dy = farn_f2(farn_ld1(FYi, o0), farn_ld1(FYi, o1));
         }
     };
-    // The R0 values and the R1 windows of the item's row, fetched one step AHEAD of their use: with the loads issued at
-    // the start of the step that needs them, a workgroup has nothing in flight while it sums, and the launch runs at the
-    // sum of its memory time and its summing time (measured: 692 us of loads — HBM-bound, 4.9 TB/s — + 393 us of sums
-    // = 1011 us per launch).  Held in registers across the sums of the step before.
+    // The R0 values of the item's row (like its flow) are fetched one step AHEAD of their use and held in registers across
+    // the sums of the step before: 10 registers that keep loads in flight while the workgroup sums.  The R1 windows are
+    // loaded when they are used — holding them too (40 registers) costs the fourth workgroup per CU and measures 3 % slower
+    // (166 registers, 3 workgroups: 988-995 us per launch; this form, 126 registers, 4 workgroups: 962-967 us;
+    // profiles/round4/farn_iter/stream_prefetch_rates.txt).
     float pr0[2][5];
-    f4 pw0[5], pw1[5];
-    auto joint_of = [&](const FarnGeo &ga, const FarnGeo &gb) {
-        return ga.valid && gb.valid && gb.y1 == ga.y1 && (unsigned)(gb.x1 - ga.x1) <= 2u && ga.x1 + 3 <= w - 1;
-    };
-    auto issue_row = [&](int gy, f2 dx, f2 dy) {
+    auto issue_row = [&](int gy) {
         if (xin) {
             const unsigned o = (unsigned)(gy * pitch + gx[0]) * 4u;
 #pragma unroll
@@ -915,36 +912,14 @@ __global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnP
                     pr0[j][p] = farn_ld1(R0 + p * ps, o);
             }
         }
-        const FarnGeo ga = farn_geo(gx[0], gy, dx.x, dy.x, w, h);
-        const FarnGeo gb = farn_geo(gx[1], gy, dx.y, dy.y, w, h);
-        if (joint_of(ga, gb)) { // the 16-byte windows both pixels sample from (farn_sample_pair); other lanes gather late
-            const unsigned qa = (unsigned)(ga.y1 * pitch + ga.x1) * 4u, qa1 = qa + (unsigned)pitch * 4u;
-#pragma unroll
-            for (int p = 0; p < 5; ++p) {
-                pw0[p] = farn_ld4u(R1 + p * ps, qa);
-                pw1[p] = farn_ld4u(R1 + p * ps, qa1);
-            }
-        }
     };
-    // M of the item's two pixels at image row gy (already clamped) from the prefetched values, into ring slot `slot`
+    // M of the item's two pixels at image row gy (already clamped) from the prefetched R0, into ring slot `slot`
     auto matrices_row = [&](int gy, f2 dx, f2 dy, int slot) {
         const bool unit_scale = unit_cols && gy >= 5 && gy <= h - 6;
         const FarnGeo ga = farn_geo(gx[0], gy, dx.x, dy.x, w, h);
         const FarnGeo gb = farn_geo(gx[1], gy, dx.y, dy.y, w, h);
         float va[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, vb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        const int off = gb.x1 - ga.x1;
-        if (joint_of(ga, gb)) {
-#pragma unroll
-            for (int p = 0; p < 5; ++p) {
-                const f4 t0 = pw0[p], t1 = pw1[p];
-                va[p] = farn_bilinear(ga, farn_f2(t0.x, t0.y), farn_f2(t1.x, t1.y));
-                const f2 b0 = off == 0 ? farn_f2(t0.x, t0.y) : off == 1 ? farn_f2(t0.y, t0.z) : farn_f2(t0.z, t0.w);
-                const f2 b1 = off == 0 ? farn_f2(t1.x, t1.y) : off == 1 ? farn_f2(t1.y, t1.z) : farn_f2(t1.z, t1.w);
-                vb[p] = farn_bilinear(gb, b0, b1);
-            }
-        } else {
-            farn_sample_pair(R1, ps, w, pitch, ga, gb, va, vb); // takes its per-pixel branch for these lanes
-        }
+        farn_sample_pair(R1, ps, w, pitch, ga, gb, va, vb);
         f2 m02[2], m34[2];
         float m1[2];
         farn_um_finish(ga.valid, va, pr0[0], dx.x, dy.x, gx[0], gy, w, h, unit_scale, m02[0], m34[0], m1[0]);
@@ -985,11 +960,11 @@ __global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnP
         load_flow(image_row(k1), dx0, dy0);
         load_flow(image_row(RB + k1), dx1, dy1);
         load_flow(image_row(2 * RB + k1), cdx, cdy);
-        issue_row(image_row(k1), dx0, dy0);
+        issue_row(image_row(k1));
         matrices_row(image_row(k1), dx0, dy0, k1);
-        issue_row(image_row(RB + k1), dx1, dy1);
+        issue_row(image_row(RB + k1));
         matrices_row(image_row(RB + k1), dx1, dy1, RB + k1);
-        issue_row(image_row(2 * RB + k1), cdx, cdy);
+        issue_row(image_row(2 * RB + k1));
         load_flow(image_row(3 * RB + k1), ndx, ndy);
     }
     const int n_steps = (yb - ya + RB - 1) / RB;
@@ -1003,7 +978,7 @@ __global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnP
             matrices_row(image_row(2 * RB + RB * s + k1), cdx, cdy, slot);
             if (s + 1 < n_steps) { // the next step's loads fly while this step sums; the flows of the step after it, too
                 cdx = ndx, cdy = ndy;
-                issue_row(image_row(2 * RB + RB * (s + 1) + k1), cdx, cdy);
+                issue_row(image_row(2 * RB + RB * (s + 1) + k1));
                 if (s + 2 < n_steps)
                     load_flow(image_row(2 * RB + RB * (s + 2) + k1), ndx, ndy);
             }
