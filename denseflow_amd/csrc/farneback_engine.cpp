@@ -317,7 +317,8 @@ int FarnebackEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, lo
         if (fused) {
             HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
             for (int it = 0; it < p.farn_num_iters; ++it) {
-                farn_launch_iter_stream(c->stream, x, set, set ^ 1, box_inv);
+                const bool last = k == 0 && it == p.farn_num_iters - 1; // writes the output rows itself: no merge launch
+                farn_launch_iter_stream(c->stream, x, set, set ^ 1, box_inv, last ? d_out : nullptr, out_stride);
                 set ^= 1;
             }
             HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));
@@ -338,8 +339,10 @@ int FarnebackEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, lo
         set ^= 1; // the next (finer) level is initialised into the other set, from the one this level ended in
     }
     set ^= 1;     // the set level 0 ended in
-    farn_launch_merge(c->stream, x, set, d_out, out_stride);
-    c->stats.kernel_launches += 1;
+    if (!fused) {
+        farn_launch_merge(c->stream, x, set, d_out, out_stride);
+        c->stats.kernel_launches += 1;
+    }
     return DFX_OK;
 }
 

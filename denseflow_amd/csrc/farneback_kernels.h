@@ -65,5 +65,7 @@ void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, in
                            int do_matrices, int impl);
 // the iteration with M recomputed where the box filter needs it (winSize 13 only): reads flow set flow_in, writes flow
 // set flow_out; a stream down 64-column strips with a ring of 18 M rows in LDS (round 4's default)
-void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv);
+// merged != nullptr (the last iteration of level 0): the new flow goes to the caller's interleaved (u, v) rows instead
+void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv, float *merged,
+                             long long merged_stride);
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride);

@@ -848,7 +848,7 @@ __device__ __forceinline__ void farn_sample_pair(const float *__restrict__ R1, u
 #endif
 template <int HALF>
 __global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnPairCtx c, int flow_in, int flow_out, float box_inv,
-                                                             int seg_rows) {
+                                                             int seg_rows, float *merged, long long merged_stride) {
     constexpr int TW = 64, IW = TW + 2 * HALF, RB = 6, RING = RB + 2 * HALF, NP = IW / 2; // 38 column pairs per row
     static_assert(HALF == 6 && RING == 18 && RB * NP <= 256 && RB * (TW / 2) <= 256, "work split worked out for 6-row steps");
     __shared__ __attribute__((aligned(16))) f2 A[RING][IW];    // (M0, M2)
@@ -1067,7 +1067,14 @@ __global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnP
                 fyo[i] = (g22 * h1 - g12 * h2) * detInv;
             }
             const unsigned o = (unsigned)(y * pitch + x);
-            if (x + 1 < w) { // x is even and the pitch a multiple of 64: 8-byte stores
+            if (merged) {
+                // the last iteration of level 0 writes the caller's interleaved (u, v) rows itself (k_farn_merge's job:
+                // one launch and 16 B/px of traffic less per pair); w may be odd, so an 8-byte store per pixel
+                float2 *dst = reinterpret_cast<float2 *>(merged + (long long)b * merged_stride) + ((long long)y * w + x);
+                dst[0] = make_float2(fxo[0], fyo[0]);
+                if (x + 1 < w)
+                    dst[1] = make_float2(fxo[1], fyo[1]);
+            } else if (x + 1 < w) { // x is even and the pitch a multiple of 64: 8-byte stores
                 *reinterpret_cast<float2 *>(FXo + o) = make_float2(fxo[0], fxo[1]);
                 *reinterpret_cast<float2 *>(FYo + o) = make_float2(fyo[0], fyo[1]);
             } else {
@@ -1182,10 +1189,12 @@ int farn_stream_seg_rows(int w, int h, int n_pairs) {
     return (rows + 5) / 6 * 6;
 }
 
-void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv) {
+void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv, float *merged,
+                             long long merged_stride) {
     const int seg_rows = farn_stream_seg_rows(c.L.w, c.L.h, c.n_pairs);
     const dim3 grid((c.L.w + 63) / 64, (c.L.h + seg_rows - 1) / seg_rows, c.n_pairs);
-    hipLaunchKernelGGL(k_farn_iter_stream<6>, grid, dim3(256), 0, s, c, flow_in, flow_out, box_inv, seg_rows);
+    hipLaunchKernelGGL(k_farn_iter_stream<6>, grid, dim3(256), 0, s, c, flow_in, flow_out, box_inv, seg_rows, merged,
+                       merged_stride);
 }
 
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride) {
