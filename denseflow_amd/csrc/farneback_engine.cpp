@@ -271,16 +271,24 @@ int FarnebackEngine::build_frames(const unsigned char *d_src, long long src_fram
     std::memcpy(h_slots_pinned, h_slots, sizeof(int) * n);
     HIPCHK(c, hipMemcpyAsync(d_frame_slots, h_slots_pinned, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
     const int W = c->W, H = c->H;
-    farn_launch_u8_to_f32(c->stream, d_src, src_frame_stride, src_pitch, n, d_f32, plane_stride, W, H, pitch0);
+    // The vertical blur reads the 8-bit frames themselves unless the cross-check form is asked for
+    // (DFX_VAR_FARN_EVAL_ZERO_TAPS: the round-1 chain with its separate convertTo pass; same bits either way).
+    const bool from_u8 = skip_zero_weights != 0;
+    if (!from_u8)
+        farn_launch_u8_to_f32(c->stream, d_src, src_frame_stride, src_pitch, n, d_f32, plane_stride, W, H, pitch0);
     for (int k = nlev - 1; k >= 0; --k) {
         const FLevel &L = lv[k];
-        farn_launch_blur_v(c->stream, d_f32, plane_stride, n, W, H, pitch0, L.g.h, L.ify, d_gker + L.ker_off, L.half,
-                           d_tmpv, plane_stride * 2, skip_zero_weights);
+        if (from_u8)
+            farn_launch_blur_v_u8(c->stream, d_src, src_frame_stride, src_pitch, n, W, H, pitch0, L.g.h, L.ify,
+                                  d_gker + L.ker_off, L.half, d_tmpv, plane_stride * 2, skip_zero_weights);
+        else
+            farn_launch_blur_v(c->stream, d_f32, plane_stride, n, W, H, pitch0, L.g.h, L.ify, d_gker + L.ker_off, L.half,
+                               d_tmpv, plane_stride * 2, skip_zero_weights);
         farn_launch_blur_h_resize(c->stream, d_tmpv, plane_stride * 2, n, W, H, pitch0, L.g.w, L.g.h, L.g.pitch, L.ifx,
                                   L.ify, d_gker + L.ker_off, L.half, d_pyr, plane_stride, skip_zero_weights);
         farn_launch_polyexp(c->stream, d_pyr, plane_stride, n, d_frame_slots, d_R, frame_elems, L.g, pc, polyexp_rows);
     }
-    c->stats.kernel_launches += 1 + 3 * nlev;
+    c->stats.kernel_launches += (from_u8 ? 0 : 1) + 3 * nlev;
     return DFX_OK;
 }
 
@@ -301,9 +309,36 @@ int FarnebackEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, lo
     x.pairs = d_pairs;
     x.n_pairs = nb;
     // M recomputed inside the iteration kernel (round 4) unless the window is not the reference's 13 or a cross-check
-    // form is asked for; the M-in-HBM kernels need the first updateMatrices launch of every level
+    // form is asked for
     const bool fused = p.impl == 0 && half == 6 && !(p.variant & DFX_VAR_FARN_M_IN_HBM);
-    int set = (nlev - 1) & 1; // flow set the level's iterations start from (the previous level ended in the other one)
+    if (fused) {
+        // One launch per iteration and nothing else: the first iteration of a level up-samples the coarser level's flow
+        // itself (zero at the coarsest), the last one of level 0 writes the caller's interleaved rows.  The flow
+        // ping-pongs between its two plane sets; `cur` = the set the latest flow is in.
+        int cur = 0;
+        for (int k = nlev - 1; k >= 0; --k) {
+            x.L = lv[k].g;
+            const bool top = k == nlev - 1;
+            const FarnLevelGeom P = top ? lv[k].g : lv[k + 1].g;
+            const float ifx = top ? 0.f : (float)(1.0 / ((double)x.L.w / (double)P.w));
+            const float ify = top ? 0.f : (float)(1.0 / ((double)x.L.h / (double)P.h));
+            HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
+            for (int it = 0; it < p.farn_num_iters; ++it) {
+                const bool last = k == 0 && it == p.farn_num_iters - 1;
+                float *merged = last ? d_out : nullptr;
+                if (it == 0)
+                    farn_launch_iter_stream_init(c->stream, x, cur, cur ^ 1, box_inv, merged, out_stride, P.w, P.h, P.pitch, ifx,
+                                                 ify, up, top ? 1 : 0);
+                else
+                    farn_launch_iter_stream(c->stream, x, cur, cur ^ 1, box_inv, merged, out_stride);
+                cur ^= 1;
+            }
+            HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));
+            c->stats.kernel_launches += p.farn_num_iters;
+        }
+        return DFX_OK;
+    }
+    int set = (nlev - 1) & 1; // flow set the level's iterations run in (the previous level ended in the other one)
     for (int k = nlev - 1; k >= 0; --k) {
         x.L = lv[k].g;
         if (k == nlev - 1) {
@@ -314,35 +349,22 @@ int FarnebackEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, lo
             const float ify = (float)(1.0 / ((double)x.L.h / (double)P.h));
             farn_launch_init_flow(c->stream, x, set, P.w, P.h, P.pitch, ifx, ify, up, 0); // reads set ^ 1
         }
-        if (fused) {
-            HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
-            for (int it = 0; it < p.farn_num_iters; ++it) {
-                const bool last = k == 0 && it == p.farn_num_iters - 1; // writes the output rows itself: no merge launch
-                farn_launch_iter_stream(c->stream, x, set, set ^ 1, box_inv, last ? d_out : nullptr, out_stride);
-                set ^= 1;
-            }
-            HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));
-            c->stats.kernel_launches += 1 + p.farn_num_iters;
-        } else {
-            farn_launch_update_matrices(c->stream, x, set, 0);
-            int m_src = 0;
-            HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
-            for (int it = 0; it < p.farn_num_iters; ++it) {
-                const int dm = it < p.farn_num_iters - 1;
-                farn_launch_iteration(c->stream, x, set, m_src, half, box_inv, dm, c->prm.impl);
-                if (dm)
-                    m_src ^= 1;
-            }
-            HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));
-            c->stats.kernel_launches += 2 + p.farn_num_iters;
+        farn_launch_update_matrices(c->stream, x, set, 0);
+        int m_src = 0;
+        HIPCHK(c, hipEventRecord(ev_it[k][0], c->stream));
+        for (int it = 0; it < p.farn_num_iters; ++it) {
+            const int dm = it < p.farn_num_iters - 1;
+            farn_launch_iteration(c->stream, x, set, m_src, half, box_inv, dm, c->prm.impl);
+            if (dm)
+                m_src ^= 1;
         }
+        HIPCHK(c, hipEventRecord(ev_it[k][1], c->stream));
+        c->stats.kernel_launches += 2 + p.farn_num_iters;
         set ^= 1; // the next (finer) level is initialised into the other set, from the one this level ended in
     }
-    set ^= 1;     // the set level 0 ended in
-    if (!fused) {
-        farn_launch_merge(c->stream, x, set, d_out, out_stride);
-        c->stats.kernel_launches += 1;
-    }
+    set ^= 1; // the set level 0 ended in
+    farn_launch_merge(c->stream, x, set, d_out, out_stride);
+    c->stats.kernel_launches += 1;
     return DFX_OK;
 }
 

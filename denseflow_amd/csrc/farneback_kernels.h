@@ -43,6 +43,10 @@ void farn_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long sr
 void farn_launch_blur_v(hipStream_t s, const float *frames, long long frame_stride, int n_frames, int W, int H,
                         int pitch0, int dst_h, float ify, const float *ker_half, int half, float *tmpv,
                         long long tmpv_frame_stride, int skip_zero_weights);
+// the same straight from the caller's 8-bit frames (the (float) of every load is E.2's convertTo: no u8 -> f32 pass)
+void farn_launch_blur_v_u8(hipStream_t s, const unsigned char *frames, long long frame_stride, long long src_pitch,
+                           int n_frames, int W, int H, int pitch0, int dst_h, float ify, const float *ker_half, int half,
+                           float *tmpv, long long tmpv_frame_stride, int skip_zero_weights);
 // horizontal Gaussian pass at the 2 source columns every destination pixel samples + bilinear resize
 void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_frame_stride, int n_frames, int W,
                                int H, int pitch0, int dst_w, int dst_h, int dst_pitch, float ifx, float ify,
@@ -68,4 +72,9 @@ void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, in
 // merged != nullptr (the last iteration of level 0): the new flow goes to the caller's interleaved (u, v) rows instead
 void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv, float *merged,
                              long long merged_stride);
+// the first iteration of a level: its input flow is the coarser level's final flow (plane set prev_set, that level's
+// geometry) up-sampled on the fly, or zero at the coarsest level — no init launch
+void farn_launch_iter_stream_init(hipStream_t s, const FarnPairCtx &c, int prev_set, int flow_out, float box_inv,
+                                  float *merged, long long merged_stride, int prev_w, int prev_h, int prev_pitch, float ifx,
+                                  float ify, float up, int zero);
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride);

@@ -55,8 +55,11 @@ __global__ __launch_bounds__(256) void k_farn_u8_to_f32(const unsigned char *src
 
 // tmpv[z][2*dy + r][x] = vertical Gaussian pass (B.4) of frame z at source row (r ? y2r : y1r) of
 // destination row dy (E.1 row mapping), all full-resolution columns x.
-__global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ frames, long long frame_stride, int W,
-                                                     int H, int pitch0, int dst_h, float ify,
+// SRC = unsigned char: the frames as the caller handed them over (E.2's convertTo(CV_32F) is the (float) of each load —
+// exact, so the separate u8 -> f32 pass and its plane are not needed); SRC = float: a converted plane (spitch = pitch0).
+template <class SRC>
+__global__ __launch_bounds__(256) void k_farn_blur_v(const SRC *__restrict__ frames, long long frame_stride, long long spitch,
+                                                     int W, int H, int pitch0, int dst_h, float ify,
                                                      const float *__restrict__ ker, int half,
                                                      float *__restrict__ tmpv, long long tmpv_frame_stride,
                                                      int skip_zero_weights) {
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ f
     const float sy = (float)dy * ify;
     const int y1 = (int)floorf(sy);
     const int yr0 = min(y1, H - 1), yr1 = min(y1 + 1, H - 1);
-    const float *src = frames + (long long)blockIdx.z * frame_stride;
+    const SRC *src = frames + (long long)blockIdx.z * frame_stride;
     float *out = tmpv + (long long)blockIdx.z * tmpv_frame_stride + (long long)(2 * dy) * pitch0 + x;
     // The resize weighs source row y1 + 1 with (sy - y1): exactly 0 whenever the level's scale divides the frame
     // (every level of a 2^k pyramid but the odd-sized ones).  k_farn_blur_h_resize then never reads that row, so it
@@ -79,16 +82,16 @@ __global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ f
     if (skip_zero_weights && sy - (float)y1 == 0.0f) {
         float v;
         if (yr0 - half >= 0 && yr0 + half <= H - 1) {
-            const float *c0 = src + (long long)yr0 * pitch0 + x;
-            v = c0[0] * ker[0];
+            const SRC *c0 = src + (long long)yr0 * spitch + x;
+            v = (float)c0[0] * ker[0];
 #pragma unroll 8
             for (int j = 1; j <= half; ++j)
-                v = v + (c0[-(long long)j * pitch0] + c0[(long long)j * pitch0]) * ker[j];
+                v = v + ((float)c0[-(long long)j * spitch] + (float)c0[(long long)j * spitch]) * ker[j];
         } else {
-            v = src[(long long)yr0 * pitch0 + x] * ker[0];
+            v = (float)src[(long long)yr0 * spitch + x] * ker[0];
             for (int j = 1; j <= half; ++j) {
-                const float a = src[(long long)reflect101_low(yr0 - j, H - 1) * pitch0 + x];
-                const float b = src[(long long)reflect101_high(yr0 + j, H - 1) * pitch0 + x];
+                const float a = (float)src[(long long)reflect101_low(yr0 - j, H - 1) * spitch + x];
+                const float b = (float)src[(long long)reflect101_high(yr0 + j, H - 1) * spitch + x];
                 v = v + (a + b) * ker[j];
             }
         }
@@ -96,13 +99,13 @@ __global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ f
         return;
     }
     if (yr1 == yr0 + 1 && yr0 - half >= 0 && yr1 + half <= H - 1) {
-        const float *c0 = src + (long long)yr0 * pitch0 + x, *c1 = c0 + pitch0;
-        float lo_prev = c0[0], hi_prev = c1[0]; // row yr0 - (j-1) seen from output 1, row yr1 + (j-1) from output 0
+        const SRC *c0 = src + (long long)yr0 * spitch + x, *c1 = c0 + spitch;
+        float lo_prev = (float)c0[0], hi_prev = (float)c1[0]; // row yr0 - (j-1) seen from output 1, row yr1 + (j-1) from output 0
         float v0 = lo_prev * ker[0], v1 = hi_prev * ker[0];
 #pragma unroll 8
         for (int j = 1; j <= half; ++j) {
-            const float lo = c0[-(long long)j * pitch0]; // row yr0 - j
-            const float hi = c1[(long long)j * pitch0];  // row yr1 + j
+            const float lo = (float)c0[-(long long)j * spitch]; // row yr0 - j
+            const float hi = (float)c1[(long long)j * spitch];  // row yr1 + j
             v0 = v0 + (lo + hi_prev) * ker[j];           // rows yr0 - j and yr0 + j = yr1 + (j-1)
             v1 = v1 + (lo_prev + hi) * ker[j];           // rows yr1 - j = yr0 - (j-1) and yr1 + j
             lo_prev = lo;
@@ -115,10 +118,10 @@ __global__ __launch_bounds__(256) void k_farn_blur_v(const float *__restrict__ f
 #pragma unroll
     for (int r = 0; r < 2; ++r) { // frame border: BORDER_REFLECT_101 per tap
         const int yr = r ? yr1 : yr0;
-        float v = src[(long long)yr * pitch0 + x] * ker[0];
+        float v = (float)src[(long long)yr * spitch + x] * ker[0];
         for (int j = 1; j <= half; ++j) {
-            const float a = src[(long long)reflect101_low(yr - j, H - 1) * pitch0 + x];
-            const float b = src[(long long)reflect101_high(yr + j, H - 1) * pitch0 + x];
+            const float a = (float)src[(long long)reflect101_low(yr - j, H - 1) * spitch + x];
+            const float b = (float)src[(long long)reflect101_high(yr + j, H - 1) * spitch + x];
             v = v + (a + b) * ker[j];
         }
         out[(long long)r * pitch0] = v;
@@ -846,9 +849,19 @@ __device__ __forceinline__ void farn_sample_pair(const float *__restrict__ R1, u
 #ifndef FARN_STREAM_MASK
 #define FARN_STREAM_MASK 3 // measurement builds: bit 0 = updateMatrices, bit 1 = sums + solve
 #endif
-template <int HALF>
+// INIT: the first iteration of a level.  Its input flow is not a plane set of this level but the previous (coarser)
+// level's final flow, up-sampled on the fly — resize_linear_px_f(...) * (1 / pyrScale), k_farn_init_flow's very
+// expression — or zero at the coarsest level: the init launch and its 16 B/px of traffic per level disappear.  flow_in
+// then names the set that holds the coarser level's flow (with that level's geometry, FarnInit).
+struct FarnInit {
+    int zero;                 // coarsest level: flow = 0
+    int prev_w, prev_h, prev_pitch;
+    float ifx, ify, up;
+};
+template <int HALF, bool INIT>
 __global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnPairCtx c, int flow_in, int flow_out, float box_inv,
-                                                             int seg_rows, float *merged, long long merged_stride) {
+                                                             int seg_rows, float *merged, long long merged_stride,
+                                                             FarnInit init) {
     constexpr int TW = 64, IW = TW + 2 * HALF, RB = 6, RING = RB + 2 * HALF, NP = IW / 2; // 38 column pairs per row
     static_assert(HALF == 6 && RING == 18 && RB * NP <= 256 && RB * (TW / 2) <= 256, "work split worked out for 6-row steps");
     __shared__ __attribute__((aligned(16))) f2 A[RING][IW];    // (M0, M2)
@@ -879,7 +892,16 @@ __global__ __launch_bounds__(256, FARN_STREAM_WPS) void k_farn_iter_stream(FarnP
     gx[0] = xin ? gxa : min(max(gxa, 0), w - 1);
     gx[1] = xin ? gxa + 1 : min(max(gxa + 1, 0), w - 1);
     auto load_flow = [&](int gy, f2 &dx, f2 &dy) {
-        if (xin) {
+        if (INIT) {
+            if (init.zero) {
+                dx = dy = farn_f2(0.f, 0.f);
+            } else {
+                dx = farn_f2(resize_linear_px_f(FXi, init.prev_w, init.prev_h, init.prev_pitch, gx[0], gy, init.ifx, init.ify) * init.up,
+                             resize_linear_px_f(FXi, init.prev_w, init.prev_h, init.prev_pitch, gx[1], gy, init.ifx, init.ify) * init.up);
+                dy = farn_f2(resize_linear_px_f(FYi, init.prev_w, init.prev_h, init.prev_pitch, gx[0], gy, init.ifx, init.ify) * init.up,
+                             resize_linear_px_f(FYi, init.prev_w, init.prev_h, init.prev_pitch, gx[1], gy, init.ifx, init.ify) * init.up);
+            }
+        } else if (xin) {
             const unsigned o = (unsigned)(gy * pitch + gx[0]) * 4u;
             dx = farn_ld2(FXi, o);
             dy = farn_ld2(FYi, o);
@@ -1124,8 +1146,15 @@ int farn_polyexp_rows_default() { return FARN_POLYROWS_DEFAULT; }
 void farn_launch_blur_v(hipStream_t s, const float *frames, long long frame_stride, int n_frames, int W, int H,
                         int pitch0, int dst_h, float ify, const float *ker_half, int half, float *tmpv,
                         long long tmpv_frame_stride, int skip_zero_weights) {
-    hipLaunchKernelGGL(k_farn_blur_v, grid64x4(W, dst_h, n_frames), dim3(256), 0, s, frames, frame_stride, W, H,
-                       pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride, skip_zero_weights);
+    hipLaunchKernelGGL(k_farn_blur_v<float>, grid64x4(W, dst_h, n_frames), dim3(256), 0, s, frames, frame_stride,
+                       (long long)pitch0, W, H, pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride, skip_zero_weights);
+}
+
+void farn_launch_blur_v_u8(hipStream_t s, const unsigned char *frames, long long frame_stride, long long src_pitch,
+                           int n_frames, int W, int H, int pitch0, int dst_h, float ify, const float *ker_half, int half,
+                           float *tmpv, long long tmpv_frame_stride, int skip_zero_weights) {
+    hipLaunchKernelGGL(k_farn_blur_v<unsigned char>, grid64x4(W, dst_h, n_frames), dim3(256), 0, s, frames, frame_stride,
+                       src_pitch, W, H, pitch0, dst_h, ify, ker_half, half, tmpv, tmpv_frame_stride, skip_zero_weights);
 }
 
 void farn_launch_blur_h_resize(hipStream_t s, const float *tmpv, long long tmpv_frame_stride, int n_frames, int W,
@@ -1193,8 +1222,19 @@ void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, i
                              long long merged_stride) {
     const int seg_rows = farn_stream_seg_rows(c.L.w, c.L.h, c.n_pairs);
     const dim3 grid((c.L.w + 63) / 64, (c.L.h + seg_rows - 1) / seg_rows, c.n_pairs);
-    hipLaunchKernelGGL(k_farn_iter_stream<6>, grid, dim3(256), 0, s, c, flow_in, flow_out, box_inv, seg_rows, merged,
-                       merged_stride);
+    hipLaunchKernelGGL((k_farn_iter_stream<6, false>), grid, dim3(256), 0, s, c, flow_in, flow_out, box_inv, seg_rows, merged,
+                       merged_stride, FarnInit{});
+}
+
+void farn_launch_iter_stream_init(hipStream_t s, const FarnPairCtx &c, int prev_set, int flow_out, float box_inv,
+                                  float *merged, long long merged_stride, int prev_w, int prev_h, int prev_pitch, float ifx,
+                                  float ify, float up, int zero) {
+    const int seg_rows = farn_stream_seg_rows(c.L.w, c.L.h, c.n_pairs);
+    const dim3 grid((c.L.w + 63) / 64, (c.L.h + seg_rows - 1) / seg_rows, c.n_pairs);
+    FarnInit in;
+    in.zero = zero, in.prev_w = prev_w, in.prev_h = prev_h, in.prev_pitch = prev_pitch, in.ifx = ifx, in.ify = ify, in.up = up;
+    hipLaunchKernelGGL((k_farn_iter_stream<6, true>), grid, dim3(256), 0, s, c, prev_set, flow_out, box_inv, seg_rows, merged,
+                       merged_stride, in);
 }
 
 void farn_launch_merge(hipStream_t s, const FarnPairCtx &c, int flow_set, float *out, long long out_stride) {
