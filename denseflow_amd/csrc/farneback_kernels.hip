@@ -22,6 +22,7 @@
 
 #include "dfx_device.h"
 #include "farneback_kernels.h"
+#include "farneback_plan.h"
 
 #define FARN_HALF_MAX 8 // box half-width supported by the fused iteration kernel (winSize <= 17)
 
@@ -1201,21 +1202,6 @@ void farn_launch_iteration(hipStream_t s, const FarnPairCtx &c, int flow_set, in
     }
     const dim3 grid((c.L.w + 63) / 64, (c.L.h + 15) / 16, c.n_pairs);
     hipLaunchKernelGGL(k_farn_iteration, grid, dim3(256), 0, s, c, flow_set, m_src, half, box_inv, do_matrices);
-}
-
-// Rows per segment of the streaming kernel: whole 6-row steps, and enough segments that a launch is many generations of
-// workgroups (256 CUs x 5 slots): a workgroup walks its whole segment, so with few generations the last, nearly empty
-// one costs a full segment time (one segment per column at 1080p: 3.02 generations, measured 1130 us per launch against
-// the tile kernel's 1025).  Each segment pays 12 warm-up rows.
-#ifndef FARN_STREAM_GENERATIONS
-#define FARN_STREAM_GENERATIONS 16
-#endif
-int farn_stream_seg_rows(int w, int h, int n_pairs) {
-    const long long cols = (w + 63) / 64;
-    long long nseg = (FARN_STREAM_GENERATIONS * 1280 + cols * n_pairs - 1) / (cols * n_pairs);
-    nseg = std::max<long long>(1, std::min<long long>(nseg, (h + 47) / 48)); // segments of at least 48 rows
-    const int rows = (int)((h + nseg - 1) / nseg);
-    return (rows + 5) / 6 * 6;
 }
 
 void farn_launch_iter_stream(hipStream_t s, const FarnPairCtx &c, int flow_in, int flow_out, float box_inv, float *merged,

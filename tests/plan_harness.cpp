@@ -1,6 +1,7 @@
 // tests/plan_harness.cpp — TEST INFRASTRUCTURE: C wrappers around denseflow_amd/csrc/dfx_plan.h (the pure host logic of
 // a FlowBuffer's batching, the header dfx_api.cpp compiles) so that tests/test_plan_logic.py can drive it on the CPU.
 #include "../denseflow_amd/csrc/dfx_plan.h"
+#include "../denseflow_amd/csrc/farneback_plan.h"
 
 extern "C" {
 
@@ -26,4 +27,7 @@ int ph_plan(const int *seg, int n_seg, int step, int batch, long long *out, int 
     }
     return (int)plan.size();
 }
+
+// rows per segment of the Farneback row-stream kernel's column strips
+int ph_farn_seg_rows(int w, int h, int n_pairs) { return farn_stream_seg_rows(w, h, n_pairs); }
 }

@@ -102,3 +102,21 @@ def test_one_clip_needs_batch_plus_step_frames(plan):
     # sixteen 300-frame clips, 2048-pair batches: a batch spans up to eight clips and needs their boundary frames too
     _, f_need = _plan(plan, [300] * 16, 1, 2048)
     assert 2048 + 7 <= f_need <= 2048 + 8
+
+
+@given(w=st.integers(1, 8192), h=st.integers(1, 8192), n_pairs=st.integers(1, 2048))
+@settings(max_examples=300, deadline=None)
+def test_farneback_stream_segments(plan, w, h, n_pairs):
+    """Segments of the Farneback row-stream iteration kernel (denseflow_amd/csrc/farneback_plan.h): whole 6-row steps;
+    ceil(h / rows) segments partition the rows with no empty segment; never shorter than 48 rows unless the level is (12
+    warm-up rows per segment); and as many segments as it takes for a launch to be >= 16 generations of the machine's 1024
+    workgroup slots, where the level's height allows."""
+    rows = plan.ph_farn_seg_rows(w, h, n_pairs)
+    assert rows > 0 and rows % 6 == 0
+    nseg = -(-h // rows)
+    assert (nseg - 1) * rows < h <= nseg * rows  # a partition, the last segment not empty
+    assert rows >= min(48, -(-h // 6) * 6)
+    cols = -(-w // 64)
+    wgs = cols * n_pairs * nseg
+    if wgs < 16 * 1024:  # fewer generations only where the 48-row floor (or the level's height) stops the cutting
+        assert rows >= h or rows < 2 * 48 + 6, (w, h, n_pairs, rows, nseg)
