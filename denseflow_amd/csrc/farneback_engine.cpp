@@ -138,6 +138,7 @@ class FarnebackEngine final : public AlgoEngine {
     // scratch for frame preparation, sized for n_frame_slots frames
     float *d_f32 = nullptr, *d_tmpv = nullptr, *d_pyr = nullptr;
     int skip_zero_weights = 1, polyexp_rows = 16; // frame-preparation forms, fixed when the engine is created
+    bool m_on_chip = true;                        // the default iteration kernel (M recomputed, never in HBM)
 
     int B = 0;
     float *d_planes = nullptr;
@@ -223,7 +224,10 @@ int FarnebackEngine::create() {
     HIPCHK(c, hipMemcpy(d_gker, all_taps.data(), sizeof(float) * all_taps.size(), hipMemcpyHostToDevice));
 
     plane_stride = (long long)pitch0 * H;
-    slot_stride = plane_stride * FARN_PL_COUNT;
+    // The default iteration kernel keeps M on chip: a pair slot is its two flow sets (4 planes, 33 MB at 1080p).  The
+    // M-in-HBM kernels (another window size, impl = 1, DFX_VAR_FARN_M_IN_HBM) need the two M sets as well (14 planes).
+    m_on_chip = p.impl == 0 && p.farn_win_size / 2 == 6 && !(p.variant & DFX_VAR_FARN_M_IN_HBM);
+    slot_stride = plane_stride * (m_on_chip ? (int)FARN_PL_M0 : (int)FARN_PL_COUNT);
     B = p.max_batch;
     if (B <= 0) {
         const long long px0 = (long long)W * H;
@@ -257,7 +261,8 @@ int FarnebackEngine::ensure_frame_slots(int need) {
     HIPCHK(c, hipMalloc(&d_R, (size_t)need * frame_elems * sizeof(float)));
     HIPCHK(c, hipMalloc(&d_frame_slots, sizeof(int) * need));
     HIPCHK(c, hipHostMalloc(&h_slots_pinned, sizeof(int) * need, hipHostMallocDefault));
-    HIPCHK(c, hipMalloc(&d_f32, (size_t)need * plane_stride * sizeof(float)));
+    if (!skip_zero_weights) // only the cross-check chain converts the frames to a float plane first
+        HIPCHK(c, hipMalloc(&d_f32, (size_t)need * plane_stride * sizeof(float)));
     HIPCHK(c, hipMalloc(&d_tmpv, (size_t)need * plane_stride * 2 * sizeof(float)));
     HIPCHK(c, hipMalloc(&d_pyr, (size_t)need * plane_stride * sizeof(float)));
     n_frame_slots = need;
@@ -310,7 +315,7 @@ int FarnebackEngine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, lo
     x.n_pairs = nb;
     // M recomputed inside the iteration kernel (round 4) unless the window is not the reference's 13 or a cross-check
     // form is asked for
-    const bool fused = p.impl == 0 && half == 6 && !(p.variant & DFX_VAR_FARN_M_IN_HBM);
+    const bool fused = m_on_chip;
     if (fused) {
         // One launch per iteration and nothing else: the first iteration of a level up-samples the coarser level's flow
         // itself (zero at the coarsest), the last one of level 0 writes the caller's interleaved rows.  The flow
