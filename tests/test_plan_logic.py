@@ -118,5 +118,6 @@ def test_farneback_stream_segments(plan, w, h, n_pairs):
     assert rows >= min(48, -(-h // 6) * 6)
     cols = -(-w // 64)
     wgs = cols * n_pairs * nseg
-    if wgs < 16 * 1024:  # fewer generations only where the 48-row floor (or the level's height) stops the cutting
+    if wgs < 0.85 * 16 * 1024:  # (rounding a segment up to whole steps costs a few segments) fewer generations only where
+        # the 48-row floor or the level's height stops the cutting
         assert rows >= h or rows < 2 * 48 + 6, (w, h, n_pairs, rows, nseg)
