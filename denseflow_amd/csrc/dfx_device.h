@@ -33,7 +33,7 @@ struct Tvl1Consts {
     float l_t;   // (float)(lambda*theta)
     float taut;  // (float)(tau/theta)
     float theta; // (float)theta
-    float pad_;
+    int hyp;     // hypot reading of the exact arithmetic (tvl1_math.h: TVL1_HYP_*) for the scalar kernel forms
 };
 
 // Everything a TVL1 kernel needs for one level; passed by value as the kernel argument.

@@ -114,8 +114,10 @@ int Tvl1Engine::create() {
         return dfx_fail(c, DFX_ERR_INVALID, "invalid TVL1 parameters");
     if (p.impl < 0 || p.impl > 2)
         return dfx_fail(c, DFX_ERR_INVALID, "tvl1: impl must be 0 (tuned), 1 (simple) or 2 (scalar tile function)");
-    if (p.tvl1_math < 0 || p.tvl1_math > 1 || (p.tvl1_math == 1 && p.impl != 0))
-        return dfx_fail(c, DFX_ERR_INVALID, "tvl1_math must be 0 (exact) or 1 (fast; tuned kernel only)");
+    if (p.tvl1_math < 0 || p.tvl1_math > 3 || (p.tvl1_math == 1 && p.impl != 0))
+        return dfx_fail(c, DFX_ERR_INVALID,
+                        "tvl1_math must be 0 (exact), 1 (fast; tuned kernel only), 2 (exact, sqrtf hypot) or 3 (exact, "
+                        "libm hypot)");
     group_override = std::max(0, std::min(p.step_group, 64));
     // the dedicated warp kernel does not write the grad plane: only the packed tile function (impl 0) rebuilds it;
     // zero iterations: warps inside the step kernel
@@ -151,6 +153,7 @@ int Tvl1Engine::create() {
     kc.l_t = (float)(p.tvl1_lambda * p.tvl1_theta);
     kc.taut = (float)(p.tvl1_tau / p.tvl1_theta);
     kc.theta = (float)p.tvl1_theta;
+    kc.hyp = p.tvl1_math == 1 ? 0 : p.tvl1_math; // tvl1_math.h: TVL1_HYP_* (the fast mode never reaches a scalar form)
 
     // batch: enough pairs that the coarse levels fill 256 CUs, bounded by memory
     const long long plane = (long long)lv[0].pitch * c->H;

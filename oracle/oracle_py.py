@@ -163,6 +163,7 @@ def _bind_all(L):
 # reading variants (oracle_common.h): flags for `variant(...)`
 VAR_TVL1_BREAK_BEFORE_DUAL, VAR_TVL1_SUM_FLOAT, VAR_TVL1_SQRT_HYPOT = 1, 2, 4
 VAR_FARN_SIGMA0_COMPUTED, VAR_BROX_JACOBI, VAR_BROX_CONVERT_DOUBLE = 8, 16, 32
+VAR_TVL1_LIBM_HYPOT = 64
 
 
 class variant:
