@@ -194,11 +194,31 @@ int grow_jpeg_streams(dfx_context *c, unsigned long long need) {
     (void)dfx_finish_tails(c, 0, -1); // a deferred tail may still be reading a landing buffer
     HIPCHK(c, hipDeviceSynchronize());
     const size_t cap = (((size_t)need + (size_t)need / 4 + (64u << 10)) + 255) & ~(size_t)255;
+    // All four new buffers first, swapped in only when every allocation has succeeded: a failure part-way leaves the
+    // encoder exactly as it was (old buffers, old capacity) and the call reports the error.
+    unsigned *nd[2] = {nullptr, nullptr};
+    unsigned char *nh[2] = {nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    for (int p = 0; p < 2 && e == hipSuccess; ++p) {
+        e = hipMalloc((void **)&nd[p], cap);
+        if (e == hipSuccess)
+            e = hipHostMalloc((void **)&nh[p], cap, hipHostMallocDefault);
+    }
+    if (e != hipSuccess) {
+        for (int p = 0; p < 2; ++p) {
+            if (nd[p])
+                (void)hipFree(nd[p]);
+            if (nh[p])
+                (void)hipHostFree(nh[p]);
+        }
+        (void)hipGetLastError();
+        return dfx_fail(c, DFX_ERR_HIP, "growing the JPEG stream buffers failed; the encoder keeps its old buffers");
+    }
     for (int p = 0; p < 2; ++p) {
         dfx_free_dev(j.d_stream[p]);
         dfx_free_host(j.h_stream[p]);
-        HIPCHK(c, hipMalloc(&j.d_stream[p], cap));
-        HIPCHK(c, hipHostMalloc(&j.h_stream[p], cap, hipHostMallocDefault));
+        j.d_stream[p] = nd[p];
+        j.h_stream[p] = nh[p];
     }
     j.capacity = cap;
     return DFX_OK;

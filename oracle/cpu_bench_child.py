@@ -5,6 +5,10 @@
         kind = cpu_tvl1 : oracle/cpu_tvl1_baseline.c, the restatement of CPU cv::optflow::DualTVL1OpticalFlow
                           (the comparator BASELINE.json's north_star names), built here with -O3 -march=native
                tvl1 | farn | brox : the parity oracle (cv::cuda semantics), timed as a second CPU point
+    python oracle/cpu_bench_child.py <in.npz> parity:<tvl1|farn|brox> <out.npz>
+        bench.py's `parity_check`: the parity oracle's flows (and, TVL1, executed iteration tables) of the listed pairs
+        of the very frames the timed run used.  in.npz: frames (n,H,W) u8, pairs (k,2) indices into frames, params (JSON:
+        TVL1 parameter overrides).  out.npz: flow_<i>, iters_<i>.  The checker, never the thing measured.
 
 A child process so that the OpenMP runtime starts with a placement chosen HERE, before any library is loaded:
 one thread per physical core of the CPUs this process may run on, pinned (GOMP_CPU_AFFINITY).  Round 1 timed the
@@ -61,7 +65,8 @@ def cgroup_cpu_quota():
 
 
 def main():
-    path, kind, budget = sys.argv[1], sys.argv[2], float(sys.argv[3])
+    path, kind, budget_arg = sys.argv[1], sys.argv[2], sys.argv[3]
+    budget = 0.0 if kind.startswith("parity:") else float(budget_arg)
     min_pairs = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # >= 10 pairs for the headline comparator
     allowed = os.sched_getaffinity(0)
     cpus = physical_cores(allowed)
@@ -82,11 +87,34 @@ def main():
 
     from oracle import oracle_py as O
 
-    frames = np.load(path)
     O.build()
+    if kind.startswith("parity:"):
+        algo = kind.split(":", 1)[1]
+        z = np.load(path)
+        frames, pairs = z["frames"], z["pairs"]
+        over = json.loads(str(z["params"])) if "params" in z.files else {}
+        out = {}
+        O.tvl1_calc(np.zeros((160, 160), np.uint8), np.zeros((160, 160), np.uint8), threads=len(cpus))  # thread team up
+        t0 = time.perf_counter()
+        for i, (a, b) in enumerate(pairs):
+            if algo == "tvl1":
+                prm = O.tvl1_default_params()
+                for k, v in over.items():
+                    setattr(prm, k, type(getattr(prm, k))(v))
+                flow, tr = O.tvl1_calc(frames[a], frames[b], prm, want_trace=True, threads=len(cpus))
+                out[f"iters_{i}"] = np.array([r[:5] for r in tr.iters_table()[:tr.nscales]], np.int32)
+            else:
+                flow = {"farn": O.farneback_calc, "brox": O.brox_calc}[algo](frames[a], frames[b], threads=len(cpus))
+            out[f"flow_{i}"] = flow
+        dt = time.perf_counter() - t0
+        np.savez(budget_arg, **out)
+        print(json.dumps({"pairs": int(len(pairs)), "seconds": dt, "value": len(pairs) / max(dt, 1e-9),
+                          "unit": "frame-pairs/s", "cores": len(cpus)}))
+        return
+    frames = np.load(path)
     if kind == "cpu_tvl1":
         fn = lambda a, b: O.cpu_tvl1_calc(a, b, native=True)
-        what = "oracle/cpu_tvl1_baseline.c (CPU cv::optflow::DualTVL1OpticalFlow port, create() defaults), -O3 -march=native"
+        what = "oracle/cpu_tvl1_baseline.c (CPU cv::optflow::DualTVL1OpticalFlow port), -O3 -march=native"
     else:
         base = {"tvl1": O.tvl1_calc, "farn": O.farneback_calc, "brox": O.brox_calc}[kind]
         fn = lambda a, b: base(a, b, threads=len(cpus))
@@ -107,11 +135,9 @@ def main():
         "value": runs[1],
         "unit": "frame-pairs/s",
         "cores": len(cpus),
-        "runs": runs,
         "spread": (runs[2] - runs[0]) / runs[1],
-        "sample": f"median of 3 runs over {n} consecutive pairs of the same {w}x{h} clip; {what}; "
-                  f"{len(cpus)} OpenMP threads pinned one per physical core ({len(allowed)} logical CPUs visible, "
-                  f"cgroup quota {quota if quota is not None else 'none'})",
+        "sample": f"median of 3 runs over {n} consecutive pairs of the same {w}x{h} clip; {what}; {len(cpus)} threads pinned "
+                  f"one per core ({len(allowed)} CPUs visible, cgroup quota {quota if quota is not None else 'none'})",
     }))
 
 

@@ -130,12 +130,29 @@ def test_full_line_schema_and_size():
     out = json.loads(lines[0])
     cfg = out["config"]
     for k in bench.FLAT_KEYS:
-        if k.endswith("traffic_frac"):
-            continue  # PMC-derived: only where profiles/pmc_traffic.json has the algorithm at this size
+        if k.endswith("traffic_frac") or k == "parity_iters_equal":
+            continue  # PMC-derived: only with a live pass / a matching profiles/pmc_traffic.json entry; iteration tables: GPU only
         assert isinstance(cfg.get(k), float) and math.isfinite(cfg[k]), (k, cfg.get(k))
     assert all(not isinstance(v, (dict, list)) or k in ("pcie_inclusive", "other_workloads") for k, v in cfg.items())
+    # whatever the driver's record truncates must be the least important — config's keys are ordered:
+    # workload, arithmetic, the parity proof, the other BASELINE configurations' rates and fractions, the non-converging
+    # content, the other hypot readings; only then the PCIe-inclusive variants, the run's counts and the nested objects
+    keys = list(cfg)
+    assert keys[:2] == ["workload", "arithmetic"]
+    flat_present = [k for k in bench.FLAT_KEYS if k in cfg]
+    assert keys[2:2 + len(flat_present)] == flat_present
+    assert flat_present[:16] == ["parity_pairs", "parity_max_abs", "parity_legs_max_abs",
+                                 "farn_1080p_pairs_per_s", "farn_1080p_frac", "tvl1_224x64_pairs_per_s", "tvl1_224x64_frac",
+                                 "brox_4k_s2_pairs_per_s", "brox_4k_s2_frac", "tvl1_224_pairs_per_s", "tvl1_224_frac",
+                                 "tvl1_1080p_hard_pairs_per_s", "tvl1_1080p_hard_frac", "tvl1_1080p_hard_iters_per_pair",
+                                 "tvl1_1080p_noexit_pairs_per_s", "tvl1_1080p_noexit_frac"]  # (+ parity_iters_equal on a GPU)
+    assert keys.index("pcie_inclusive") > keys.index("pairs_per_step") > keys.index("tvl1_libm_pairs_per_s")
+    assert isinstance(out["parity_check"], dict) and {"pairs", "max_abs", "iters_equal"} <= set(out["parity_check"])
     legs = {leg["key"]: leg for leg in cfg["other_workloads"]}
-    assert set(legs) == {"farn_1080p", "tvl1_224", "tvl1_224x64", "brox_4k_s2"}
+    assert set(legs) == {"farn_1080p", "tvl1_224", "tvl1_224x64", "brox_4k_s2", "tvl1_1080p_hard", "tvl1_1080p_noexit",
+                         "tvl1_sqrt", "tvl1_libm"}
+    for k in ("farn_1080p", "tvl1_224", "tvl1_224x64", "brox_4k_s2"):
+        assert "max_abs" in legs[k]["parity_check"], k
     assert "x 64 in one FlowBuffer" in legs["tvl1_224x64"]["workload"] and "19136 pairs/step" in legs["tvl1_224x64"]["workload"]
     for top in ("roofline", "cpu_baseline"):
         assert isinstance(out[top], dict)

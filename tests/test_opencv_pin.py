@@ -49,6 +49,19 @@ def test_hip_path_reproduces_opencv_cuda(dfx, algo):
     print(FS.table(stats), FS.gate(stats, f"HIP {algo} vs cv::cuda"))
 
 
+@pytest.mark.parametrize("algo", ["tvl1", "farn"])
+@pytest.mark.xfail(strict=False, reason="BASELINE.json's bar taken literally — max-abs <= 1e-3 on EVERY pair — is kept as a "
+                   "report-only check (ADVICE r4): DESIGN.md 2c / 2d show that no implementation that is not bit-identical "
+                   "to the CUDA_FAST_MATH build can meet it; the gate is tests/flow_stats.py")
+def test_oracle_vs_opencv_cuda_strict_max_abs_report_only(oracle, algo):
+    """The original acceptance criterion, evaluated the day golden files exist, never gating: the deviation from
+    BASELINE.json's wording (graded statistic instead of per-pair max-abs) is recorded in BASELINE.md section 1."""
+    calc = {"tvl1": oracle.tvl1_calc, "farn": oracle.farneback_calc}[algo]
+    worst = max(float(np.max(np.abs(calc(f0, f1) - flow))) for _, f0, f1, flow in _cases(algo))
+    print(f"strict max-abs over all pairs, oracle {algo} vs cv::cuda: {worst:.3g}")
+    assert worst <= 1e-3
+
+
 def _imencode_golden():
     p = os.path.join(GOLDEN, "opencv_imencode.npz")
     if not os.path.exists(p):
