@@ -116,6 +116,23 @@ int ensure_img_staging(dfx_context *c, int img_need) {
     return DFX_OK;
 }
 
+int ensure_png(dfx_context *c, int need) {
+    if (need > c->png_slots) {
+        (void)dfx_finish_tails(c, 0, -1);
+        HIPCHK(c, hipDeviceSynchronize());
+        c->png_slots = 0;
+        dfx_free_dev(c->d_png_scratch);
+        HIPCHK(c, hipMalloc(&c->d_png_scratch, quant_png_scratch_bytes(need)));
+        for (int p = 0; p < 2; ++p) {
+            dfx_free_host(c->h_png_bounds[p]);
+            HIPCHK(c, hipHostMalloc((void **)&c->h_png_bounds[p], (size_t)need * 2 * sizeof(double), hipHostMallocMapped));
+            HIPCHK(c, hipHostGetDevicePointer((void **)&c->d_png_bounds[p], c->h_png_bounds[p], 0));
+        }
+        c->png_slots = need;
+    }
+    return DFX_OK;
+}
+
 int ensure_src_staging(dfx_context *c, int need) {
     const size_t fb = c->in_row_bytes() * c->in_h();
     if (need > c->src_slots || fb != c->src_frame_bytes) {
@@ -286,6 +303,10 @@ struct OutSpec {
     size_t img_pitch = 0;                                     // bytes per row (host and device mode)
     uint8_t *d_img_x = nullptr, *d_img_y = nullptr;           // device mode: plane i at + i*d_img_stride
     size_t d_img_stride = 0;
+    // the -st=png scheme (implies quantized; lo / hi unused): planes scaled by the reference's per-flow adaptive bounds,
+    // which go to bounds[2 * i] = {bound_x, bound_y} (host mode: filled when the call returns) or d_bounds (device mode)
+    bool png = false;
+    double *bounds = nullptr, *d_bounds = nullptr;
     // JPEG output (host mode; implies quantized): one file per plane into jpg_x[i] / jpg_y[i] (jpg_capacity bytes each)
     bool jpeg = false;
     int quality = 95;
@@ -372,6 +393,11 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
     }
     if (out.jpeg) {
         rc = ensure_jpeg(c, B, out.quality);
+        if (rc != DFX_OK)
+            return rc;
+    }
+    if (out.png) {
+        rc = ensure_png(c, B);
         if (rc != DFX_OK)
             return rc;
     }
@@ -625,7 +651,20 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         rc = E->run_pairs(p.nb, c->h_pairs.data(), dst, dst_stride);
         if (rc != DFX_OK)
             return rc;
-        if (out.quantized) { // convertFlowToImage on the device (src/common.cpp:4-16)
+        if (out.png) { // convertFlowToPngImage's bounds and planes on the device (src/common.cpp:18-46)
+            if (host_mode)
+                quant_launch_flow_to_png_planes(c->stream, dst, dst_stride, p.nb, c->W, c->H, c->d_png_scratch,
+                                                c->d_png_bounds[par(k)], c->d_img[par(k)],
+                                                c->d_img[par(k)] + (size_t)c->img_slots * plane, c->W, (long long)plane);
+            else
+                quant_launch_flow_to_png_planes(c->stream, dst, dst_stride, p.nb, c->W, c->H, c->d_png_scratch,
+                                                out.d_bounds + 2 * (size_t)p.i0,
+                                                out.d_img_x + (size_t)p.i0 * out.d_img_stride,
+                                                out.d_img_y + (size_t)p.i0 * out.d_img_stride, (long long)out.img_pitch,
+                                                (long long)out.d_img_stride);
+            HIPCHK(c, hipGetLastError());
+            c->stats.kernel_launches += 4;
+        } else if (out.quantized) { // convertFlowToImage on the device (src/common.cpp:4-16)
             if (host_mode)
                 quant_launch_flow_to_u8(c->stream, dst, dst_stride, p.nb, c->W, c->H, out.lo, out.hi, c->d_img[par(k)],
                                         c->d_img[par(k)] + (size_t)c->img_slots * plane, c->W, (long long)plane);
@@ -669,6 +708,8 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         rc = post.finish(); // batch k-1 is in the caller's buffers
         if (rc != DFX_OK)
             return rc;
+        if (out.png && host_mode) // the stream is idle: this batch's bounds are in the mapped block
+            std::memcpy(out.bounds + 2 * (size_t)p.i0, c->h_png_bounds[par(k)], (size_t)p.nb * 2 * sizeof(double));
         if (out.jpeg) { // the stream is idle: the totals of this batch are in the mapped block
             const unsigned long long *hi = c->jpeg.h_info[par(k)];
             if (hi[1] != 0) {
@@ -1112,6 +1153,67 @@ int jpeg_entry(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, i
 }
 } // namespace
 
+// the -st=png scheme (src/common.cpp:18-46, 66-71): planes scaled by the per-flow adaptive bounds + the bounds
+static int png_args(dfx_handle h, const void *frames, size_t frame_pitch, int n_frames, int step, const void *img_x,
+                    const void *img_y, size_t img_pitch, const void *bounds) {
+    const int M = std::max(n_frames - abs_step(step), 0);
+    if (M > 0 && (!frames || !img_x || !img_y || !bounds))
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL frames, image plane array or bounds array");
+    if (M > 0 && (frame_pitch < h->in_row_bytes() || img_pitch < (size_t)h->W))
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch smaller than a row");
+    return DFX_OK;
+}
+int dfx_calc_batch_png(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
+                       uint8_t *const *img_x, uint8_t *const *img_y, size_t img_pitch, double *bounds_xy) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    SegmentsScope seg_scope(h);
+    const int arc = png_args(h, frames, frame_pitch, n_frames, step, img_x, img_y, img_pitch, bounds_xy);
+    if (arc != DFX_OK)
+        return arc;
+    OutSpec out;
+    out.quantized = out.png = true;
+    out.img_x = img_x, out.img_y = img_y, out.img_pitch = img_pitch, out.bounds = bounds_xy;
+    return calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, out);
+}
+int dfx_submit_batch_png(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
+                         uint8_t *const *img_x, uint8_t *const *img_y, size_t img_pitch, double *bounds_xy,
+                         uint64_t *ticket) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    SegmentsScope seg_scope(h);
+    if (!ticket)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL ticket");
+    const int arc = png_args(h, frames, frame_pitch, n_frames, step, img_x, img_y, img_pitch, bounds_xy);
+    if (arc != DFX_OK)
+        return arc;
+    OutSpec out;
+    out.quantized = out.png = true;
+    out.img_x = img_x, out.img_y = img_y, out.img_pitch = img_pitch, out.bounds = bounds_xy;
+    unsigned long long t = 0;
+    const int rc = calc_batch_impl(h, frames, frame_pitch, nullptr, 0, 0, n_frames, step, out, &t);
+    *ticket = t;
+    return rc;
+}
+int dfx_calc_batch_png_device(dfx_handle h, const uint8_t *d_frames, size_t pitch, size_t frame_stride, int n_frames,
+                              int step, uint8_t *d_img_x, uint8_t *d_img_y, size_t img_pitch, size_t img_stride,
+                              double *d_bounds_xy) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    SegmentsScope seg_scope(h);
+    const int M = std::max(n_frames - abs_step(step), 0);
+    if (M > 0 && (!d_frames || !d_img_x || !d_img_y || !d_bounds_xy))
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL device frames, image planes or bounds");
+    if (M > 0 && (pitch < h->in_row_bytes() || frame_stride < pitch * (size_t)h->in_h() || img_pitch < (size_t)h->W ||
+                  img_stride < img_pitch * (size_t)h->H))
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch/stride smaller than a frame");
+    OutSpec out;
+    out.quantized = out.png = true;
+    out.d_img_x = d_img_x, out.d_img_y = d_img_y, out.img_pitch = img_pitch, out.d_img_stride = img_stride;
+    out.d_bounds = d_bounds_xy;
+    return calc_batch_impl(h, nullptr, 0, d_frames, pitch, frame_stride, n_frames, step, out);
+}
+
 int dfx_calc_batch_jpeg(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
                         double lower_bound, double upper_bound, int quality, uint8_t *const *jpg_x,
                         uint8_t *const *jpg_y, size_t jpg_capacity, uint32_t *size_x, uint32_t *size_y) {
@@ -1275,6 +1377,31 @@ int dfx_flow_to_u8_device(dfx_handle h, const float *d_flows, size_t flow_stride
     return DFX_OK;
 }
 
+int dfx_flow_to_png_device(dfx_handle h, const float *d_flows, size_t flow_stride_floats, int n, uint8_t *d_img_x,
+                           uint8_t *d_img_y, size_t img_pitch, size_t img_stride, double *d_bounds_xy) {
+    if (!h)
+        return DFX_ERR_INVALID;
+    (void)dfx_finish_tails(h, 0, -1);
+    if (n < 0)
+        return dfx_fail(h, DFX_ERR_INVALID, "n must be >= 0");
+    if (n == 0)
+        return DFX_OK;
+    if (!d_flows || !d_img_x || !d_img_y || !d_bounds_xy)
+        return dfx_fail(h, DFX_ERR_INVALID, "NULL device flows, image planes or bounds");
+    if (flow_stride_floats < (size_t)h->W * h->H * 2 || img_pitch < (size_t)h->W ||
+        img_stride < img_pitch * (size_t)h->H)
+        return dfx_fail(h, DFX_ERR_INVALID, "pitch/stride smaller than a frame");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int rc = ensure_png(h, n);
+    if (rc != DFX_OK)
+        return rc;
+    quant_launch_flow_to_png_planes(h->stream, d_flows, (long long)flow_stride_floats, n, h->W, h->H, h->d_png_scratch,
+                                    d_bounds_xy, d_img_x, d_img_y, (long long)img_pitch, (long long)img_stride);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DFX_OK;
+}
+
 int dfx_set_source_format(dfx_handle h, int src_width, int src_height, int channels) {
     if (!h)
         return DFX_ERR_INVALID;
@@ -1411,6 +1538,9 @@ void dfx_destroy(dfx_handle h) {
     for (auto &p : h->h_in)
         dfx_free_host(p);
     for (auto &p : h->h_out)
+        dfx_free_host(p);
+    dfx_free_dev(h->d_png_scratch);
+    for (auto &p : h->h_png_bounds)
         dfx_free_host(p);
     free_jpeg(h);
     for (auto &e : h->ev_h2d)

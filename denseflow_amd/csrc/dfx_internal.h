@@ -92,6 +92,11 @@ struct dfx_context {
     size_t h_in_bytes = 0, h_out_bytes = 0;
     unsigned char *d_img[2] = {nullptr, nullptr}; // bounded output: img_slots x planes, then img_slots y planes
     int img_slots = 0;
+    // the -st=png scheme (quantize_kernels.hip): extrema / scale scratch, and per staging parity the adaptive bounds of a
+    // batch in mapped page-locked memory (the kernel writes them, the host reads them after the batch's stream wait)
+    void *d_png_scratch = nullptr;
+    double *h_png_bounds[2] = {nullptr, nullptr}, *d_png_bounds[2] = {nullptr, nullptr};
+    int png_slots = 0;
     // device JPEG encoder (jpeg_kernels.hip): tables + per-block temporaries (one set, compute stream only), and per
     // staging parity the shared stream buffer, its page-locked landing buffer and the totals the device reports
     struct JpegState {

@@ -188,6 +188,15 @@ def load_library():
     L.dfx_wait.restype = i
     L.dfx_calc_batch_u8_device.argtypes = [vp, vp, sz, sz, i, i, C.c_double, C.c_double, vp, vp, sz, sz]
     L.dfx_calc_batch_u8_device.restype = i
+    dp = C.POINTER(C.c_double)
+    L.dfx_calc_batch_png.argtypes = [vp, C.POINTER(vp), sz, i, i, C.POINTER(vp), C.POINTER(vp), sz, dp]
+    L.dfx_calc_batch_png.restype = i
+    L.dfx_submit_batch_png.argtypes = [vp, C.POINTER(vp), sz, i, i, C.POINTER(vp), C.POINTER(vp), sz, dp, C.POINTER(C.c_uint64)]
+    L.dfx_submit_batch_png.restype = i
+    L.dfx_calc_batch_png_device.argtypes = [vp, vp, sz, sz, i, i, vp, vp, sz, sz, vp]
+    L.dfx_calc_batch_png_device.restype = i
+    L.dfx_flow_to_png_device.argtypes = [vp, vp, sz, i, vp, vp, sz, sz, vp]
+    L.dfx_flow_to_png_device.restype = i
     L.dfx_flow_to_u8_device.argtypes = [vp, vp, sz, i, C.c_double, C.c_double, vp, vp, sz, sz]
     L.dfx_flow_to_u8_device.restype = i
     L.dfx_set_source_format.argtypes = [vp, i, i, i]
@@ -431,6 +440,64 @@ class FlowEngine:
         self._check(self._L.dfx_calc_batch_u8(self._h, fp, frames[0].strides[0], n, int(step), lo, float(bound), xp,
                                               yp, self.width))
         return img_x, img_y
+
+    # -- the -st=png scheme on the device (reference: convertFlowToPngImage, src/common.cpp:18-46) ------
+    def calc_optflows_png(self, frames_gray, step: int, submit: bool = False):
+        """calc_optflows followed by convertFlowToPngImage's arithmetic on the device: per flow the adaptive bounds
+        (minMaxLoc, the ceil(.../4)*4 rule with its `% 8 == 0 -> += 4` step) and the two convertTo(CV_8U) planes.
+
+        Returns (img_x, img_y, bounds): two lists of M (H, W) uint8 planes and an (M, 2) float64 array of
+        (bound_x, bound_y).  png_bgr() assembles the reference's 3-channel image from them.  submit=True goes through
+        dfx_submit_batch_png + dfx_wait (the host shell's form)."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames_gray]
+        n = len(frames)
+        m = self._num_pairs(n, step)
+        img_x = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
+        img_y = [np.empty((self.height, self.width), dtype=np.uint8) for _ in range(m)]
+        bounds = np.zeros((m, 2), np.float64)
+        if m == 0:
+            return img_x, img_y, bounds
+        for f in frames:
+            if f.shape != self._frame_shape():
+                raise ValueError("frame shape does not match the engine")
+        fp = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        xp = (C.c_void_p * m)(*[f.ctypes.data for f in img_x])
+        yp = (C.c_void_p * m)(*[f.ctypes.data for f in img_y])
+        bp = bounds.ctypes.data_as(C.POINTER(C.c_double))
+        self._arm()
+        if submit:
+            t = C.c_uint64(0)
+            self._check(self._L.dfx_submit_batch_png(self._h, fp, frames[0].strides[0], n, int(step), xp, yp, self.width,
+                                                     bp, C.byref(t)))
+            self._check(self._L.dfx_wait(self._h, t.value))
+        else:
+            self._check(self._L.dfx_calc_batch_png(self._h, fp, frames[0].strides[0], n, int(step), xp, yp, self.width, bp))
+        return img_x, img_y, bounds
+
+    def calc_optflows_png_device(self, d_frames_ptr: int, pitch: int, frame_stride: int, n_frames: int, step: int,
+                                 d_img_x_ptr: int, d_img_y_ptr: int, img_pitch: int, img_stride: int, d_bounds_ptr: int):
+        self._num_pairs(n_frames, step)
+        self._arm()
+        self._check(self._L.dfx_calc_batch_png_device(self._h, d_frames_ptr, pitch, frame_stride, n_frames, int(step),
+                                                      d_img_x_ptr, d_img_y_ptr, img_pitch, img_stride, d_bounds_ptr))
+
+    def flow_to_png_device(self, d_flows_ptr: int, flow_stride_floats: int, n: int, d_img_x_ptr: int, d_img_y_ptr: int,
+                           img_pitch: int, img_stride: int, d_bounds_ptr: int):
+        self._check(self._L.dfx_flow_to_png_device(self._h, d_flows_ptr, flow_stride_floats, n, d_img_x_ptr, d_img_y_ptr,
+                                                   img_pitch, img_stride, d_bounds_ptr))
+
+    @staticmethod
+    def png_bgr(img_x: np.ndarray, img_y: np.ndarray, bound_x: float, bound_y: float) -> np.ndarray:
+        """The reference's 3-channel PNG image (src/common.cpp:41-45) from the device's planes and bounds: channel 2 is
+        bound_x / 4 on rows 0 .. int(H / 2) (rectangle's inclusive box, Point's truncation) and bound_y / 4 below."""
+        h, w = img_x.shape
+        out = np.empty((h, w, 3), np.uint8)
+        out[..., 0], out[..., 1] = img_x, img_y
+        half = int(h / 2)
+        sat = lambda v: int(min(255, max(0, np.rint(v))))  # noqa: E731 — saturate_cast<uchar>(double): cvRound, clamp
+        out[: half + 1, :, 2] = sat(bound_x / 4)
+        out[half + 1:, :, 2] = sat(bound_y / 4)
+        return out
 
     def calc_optflows_jpeg(self, frames_gray, step: int, bound: float, quality: int = 95):
         """encodeFlowMap of every flow of the FlowBuffer on the device (src/common.cpp:48-64): returns two lists of

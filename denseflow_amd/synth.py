@@ -167,7 +167,42 @@ class HardClip:
         return [self.frame(start + i) for i in range(n)]
 
     def frames_torch(self, n: int, device, start: int = 0):
-        """(n, H, W) uint8 on `device`; the frames of frame() (NumPy on the host: a bench leg needs a few dozen)."""
+        """(n, H, W) uint8 on `device`, generated there with float64 torch math (bench only: like SynthClip.frames_torch the
+        texture values may differ from frame() by 1 LSB in rare pixels; the noise is torch's generator on that device,
+        seeded per frame — reproducible on a given machine, not equal to frame()'s NumPy noise.  bench.py checks parity on
+        the frames it downloads from the device, so this does not matter)."""
         import torch
 
-        return torch.from_numpy(np.stack(self.frames(n, start))).to(device)
+        if torch.device(device).type == "cpu" and not getattr(self, "_force_torch_math", False):
+            return torch.from_numpy(np.stack(self.frames(n, start)))
+        w, h = self.width, self.height
+        x = torch.arange(w, dtype=torch.float64, device=device)[None, :]
+        y = torch.arange(h, dtype=torch.float64, device=device)[:, None]
+        cx, cy = (w - 1) * 0.5, (h - 1) * 0.5
+
+        def texture(clip, X, Y):
+            fx = torch.tensor(clip.fx, dtype=torch.float64, device=device)
+            fy = torch.tensor(clip.fy, dtype=torch.float64, device=device)
+            acc = torch.zeros((h, w), dtype=torch.float64, device=device)
+            for k in range(N_COMPONENTS):
+                acc += float(clip.amp[k]) * torch.sin(2.0 * math.pi * (fx[k] * X + fy[k] * Y) + float(clip.phase[k]))
+            scale, offset = clip._get_affine()
+            return acc * scale + offset
+
+        out = torch.empty((n, h, w), dtype=torch.uint8, device=device)
+        gen = torch.Generator(device=device)
+        for i in range(n):
+            t = float(start + i)
+            th = math.radians(ROTATION_DEG * t)
+            c, s = math.cos(th), math.sin(th)
+            Xb = c * (x - cx) - s * (y - cy) + cx + TRANSLATION[0] * t
+            Yb = s * (x - cx) + c * (y - cy) + cy + TRANSLATION[1] * t
+            Xf, Yf = x - self.FG_TRANSLATION[0] * t, y - self.FG_TRANSLATION[1] * t
+            mask = torch.zeros((h, w), dtype=torch.float64, device=device)
+            for k in range(len(self.mph)):
+                mask += torch.sin(2.0 * math.pi * (float(self.mfx[k]) * Xf + float(self.mfy[k]) * Yf) + float(self.mph[k]))
+            v = torch.where(mask > 0.0, texture(self.fg, Xf, Yf), texture(self.bg, Xb, Yb))
+            gen.manual_seed(self.seed * 1000003 + int(start + i))
+            v = v + torch.randn((h, w), dtype=torch.float64, device=device, generator=gen) * self.NOISE_SIGMA
+            out[i] = torch.clamp(torch.round(v), 0, 255).to(torch.uint8)
+        return out

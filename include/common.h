@@ -97,6 +97,9 @@ void convertFlowToImage(const Mat &flow_x, const Mat &flow_y, Mat &img_x, Mat &i
 void encodeFlowMap(const Mat &flow_map_x, const Mat &flow_map_y, vector<uchar> &encoded_x, vector<uchar> &encoded_y,
                    int bound, bool to_jpg = true);
 void encodeFlowMapPng(const Mat &flow_map_x, const Mat &flow_map_y, vector<uchar> &encoded);
+// the same from the two convertTo planes and the adaptive bounds the device already computed (dfx_submit_batch_png):
+// interleave them with the bound channel (src/common.cpp:41-45) and encode
+void encodeFlowMapPngPlanes(const Mat &plane_x, const Mat &plane_y, double bound_x, double bound_y, vector<uchar> &encoded);
 void writeImages(vector<vector<uchar>> images, string name_prefix, const int start = 0);
 void writeFlowImages(vector<vector<uchar>> images, string name_prefix, const int step = 1, const int start = 0);
 void writeFlowImagesPng(vector<vector<uchar>> images, string name_prefix, const int step, const int start);

@@ -37,6 +37,9 @@ class FlowBuffer {
         vector<uint32_t> size_x, size_y;       // its size in bytes (valid once the FlowBuffer's ticket has been waited on)
     };
     std::shared_ptr<Encoded> encoded;
+    // Extension: the -st=png scheme's planes from the device (dfx_submit_batch_png): `bounded` planes as above, scaled by
+    // the reference's per-flow adaptive bounds; png_bounds[2i], [2i+1] = bound_x, bound_y of flow i (empty otherwise).
+    vector<double> png_bounds;
     // Extension: not a buffer of frames but the loader's early notice of the size the next video's flows will have
     // (width > 0): the flow stage creates its engine (device allocations, ~0.3 s at 1080p) while the loader reads the
     // first frames instead of after them.  Nothing is forwarded to the save stage.
@@ -101,6 +104,10 @@ class DenseFlow {
     // encodeFlowMap as a whole, src/common.cpp:48-64); the save stage only writes files.  DF_HOST_JPEG=1 keeps the
     // encoders on the host (device bounding only).
     bool device_jpeg;
+    // device_png: for save_type "png" the arithmetic of convertFlowToPngImage (src/common.cpp:18-46: minMaxLoc, the
+    // adaptive bounds, the two convertTo planes) runs on the GPU (dfx_submit_batch_png); the save stage interleaves
+    // the planes with the bound channel and calls the PNG encoder.  DF_HOST_PNG=1 keeps the float path (A/B, tests).
+    bool device_png;
     int encode_threads;
     // Extension of the load stage: a requested resize (-nw/-nh/-ns) is done by the flow stage
     // on the GPU (dfx_set_source_format) instead of cv::resize on the loader thread; DF_HOST_RESIZE=1 restores
@@ -121,6 +128,13 @@ class DenseFlow {
     FlowBufferQueue flows_queue;
     unsigned long total_frames;
     unsigned long total_flows;
+    // Where each stage's wall time goes, in microseconds (DF_TRACE / DF_STAGES print them after the run): reading /
+    // decoding frames vs blocked on the full frames queue; waiting for frames vs inside the library call; waiting for
+    // flows vs encoding + writing.  One writer per counter (its stage's thread).
+    struct StageTimes {
+        long long load_read = 0, load_push = 0, flow_pop = 0, flow_submit = 0, collect_wait = 0, collect_push = 0,
+                  save_pop = 0, save_work = 0;
+    } stage_us;
 
     // the device engine (replaces Ptr<cuda::*OpticalFlow> + cv::cuda::Stream)
     dfx_handle dfx_;

@@ -313,6 +313,44 @@ def flow_to_u8(flow: np.ndarray, lower: float, upper: float):
     return img_x, img_y
 
 
+_REF_PNG_PATH = os.path.join(_HERE, "_ref", "libref_png.so")
+_ref_png = None
+
+
+def flow_to_png_planes(flow: np.ndarray):
+    """The -st=png scheme (quant_oracle.h: orc_flow_to_png_planes).  Returns (plane_x, plane_y, (bound_x, bound_y), bgr)."""
+    flow = np.ascontiguousarray(flow, np.float32)
+    h, w = flow.shape[:2]
+    x, y = np.empty((h, w), np.uint8), np.empty((h, w), np.uint8)
+    bgr = np.empty((h, w, 3), np.uint8)
+    b = (C.c_double * 2)()
+    fn = lib().orc_flow_to_png_planes
+    fn.argtypes = [_f32p, C.c_int, C.c_int, _u8p, _u8p, C.POINTER(C.c_double), _u8p]
+    fn.restype = None
+    fn(flow, w, h, x, y, b, bgr)
+    return x, y, (b[0], b[1]), bgr
+
+
+def ref_png_available() -> bool:
+    return os.path.exists(_REF_PNG_PATH)
+
+
+def ref_flow_to_png_image(flow: np.ndarray) -> np.ndarray:
+    """The same through the reference's own source lines (oracle/_ref/libref_png.so, `make -C oracle ref`): (h, w, 3)."""
+    global _ref_png
+    if _ref_png is None:
+        R = C.CDLL(_REF_PNG_PATH)
+        R.ref_convert_flow_to_png_image.argtypes = [_f32p, _f32p, C.c_int, C.c_int, _u8p]
+        R.ref_convert_flow_to_png_image.restype = None
+        _ref_png = R
+    flow = np.ascontiguousarray(flow, np.float32)
+    h, w = flow.shape[:2]
+    fx, fy = np.ascontiguousarray(flow[..., 0]), np.ascontiguousarray(flow[..., 1])
+    out = np.empty((h, w, 3), np.uint8)
+    _ref_png.ref_convert_flow_to_png_image(fx, fy, w, h, out)
+    return out
+
+
 _ref_quant = None
 
 

@@ -27,3 +27,59 @@ void orc_flow_to_u8(const float *flow_uv, int w, int h, double lower_bound, doub
             img_y[p] = cast_bound(flow_uv[2 * p + 1], lower_bound, upper_bound);
         }
 }
+
+/* src/common.cpp:18-46. */
+static uint8_t sat_u8(double v) {
+    const int r = orc_cvround(v);
+    return (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+}
+
+static double png_bound(double extent, double mn, double mx) {
+    const double a = fabs(mn), b = fabs(mx);
+    const double m = a > b ? a : b;               /* max(abs(min_v), abs(max_v)) */
+    const double c = extent < m ? extent : m;     /* min(w, ...) */
+    double bound = ceil((c * 128. / 127.) / 4) * 4;
+    if (bound > 255. * 4)
+        bound = 255. * 4;
+    if ((int)bound % 8 == 0)
+        bound += 4;
+    return bound;
+}
+
+void orc_flow_to_png_planes(const float *flow_uv, int w, int h, uint8_t *img_x, uint8_t *img_y, double *bounds,
+                            uint8_t *img_bgr) {
+    const double base = 1. / 128.;
+    const size_t n = (size_t)w * h;
+    double mnx = flow_uv[0], mxx = flow_uv[0], mny = flow_uv[1], mxy = flow_uv[1]; /* minMaxLoc: NaNs never win */
+    for (size_t p = 0; p < n; ++p) {
+        const double u = flow_uv[2 * p], v = flow_uv[2 * p + 1];
+        if (u < mnx) mnx = u;
+        if (u > mxx) mxx = u;
+        if (v < mny) mny = v;
+        if (v > mxy) mxy = v;
+    }
+    const double bound_x = png_bound((double)w, mnx, mxx), bound_y = png_bound((double)h, mny, mxy);
+    const float ax = (float)(1. / (base * bound_x)), ay = (float)(1. / (base * bound_y));
+    const int half = (int)((double)h / 2); /* Point(w - 1, half_h): double -> int by truncation; the box is inclusive */
+    const uint8_t bx = sat_u8(bound_x / 4), by = sat_u8(bound_y / 4);
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            const size_t p = (size_t)i * w + j;
+            const float px = flow_uv[2 * p] * ax, py = flow_uv[2 * p + 1] * ay; /* convertTo: float product, float sum */
+            const float vx = px + 128.f, vy = py + 128.f;
+            const uint8_t qx = sat_u8((double)vx), qy = sat_u8((double)vy);
+            if (img_x)
+                img_x[p] = qx;
+            if (img_y)
+                img_y[p] = qy;
+            if (img_bgr) {
+                img_bgr[3 * p] = qx;
+                img_bgr[3 * p + 1] = qy;
+                img_bgr[3 * p + 2] = i <= half ? bx : by;
+            }
+        }
+    if (bounds) {
+        bounds[0] = bound_x;
+        bounds[1] = bound_y;
+    }
+}

@@ -25,6 +25,15 @@ extern "C" {
 void orc_flow_to_u8(const float *flow_uv, int w, int h, double lower_bound, double upper_bound, uint8_t *img_x,
                     uint8_t *img_y);
 
+/* The -st=png scheme, convertFlowToPngImage, /root/reference/src/common.cpp:18-46 (PARITY PINNED the same way:
+ * oracle/_ref/libref_png.so is those lines compiled against ref_png_shim.h; tests/golden/png_planes_golden.npz was
+ * minted from it).  Per flow: bound_x = min(1020, ceil((min(w, max|u|) * 128 / 127) / 4) * 4), + 4 when that integer is a
+ * multiple of 8 (bound_y with h and v); plane x = saturate_u8(u * (float)(1 / (bound_x / 128)) + 128.f) (float product,
+ * float sum, round half to even), plane y likewise; the third channel carries bound_x / 4 on rows 0 .. int(h / 2)
+ * and bound_y / 4 below.  img_x / img_y: h*w bytes; bounds[2] = {bound_x, bound_y}.  img_bgr (may be NULL): h*w*3. */
+void orc_flow_to_png_planes(const float *flow_uv, int w, int h, uint8_t *img_x, uint8_t *img_y, double *bounds,
+                            uint8_t *img_bgr);
+
 #ifdef __cplusplus
 }
 #endif

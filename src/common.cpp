@@ -183,6 +183,22 @@ void encodeFlowMapPng(const Mat &flow_map_x, const Mat &flow_map_y, vector<uchar
     imencodePng(flow_img_bgr, encoded);
 }
 
+void encodeFlowMapPngPlanes(const Mat &plane_x, const Mat &plane_y, double bound_x, double bound_y, vector<uchar> &encoded) {
+    Mat flow_img_bgr(plane_x.size(), CV_8UC3);
+    const double half_h = (double)plane_x.rows / 2;
+    for (int y = 0; y < plane_x.rows; ++y) {
+        const uchar *px = plane_x.ptr<uchar>(y), *py = plane_y.ptr<uchar>(y);
+        uchar *o = flow_img_bgr.ptr<uchar>(y);
+        const uchar b = (y <= (int)half_h) ? saturate_u8(bound_x / 4) : saturate_u8(bound_y / 4); // as in convertFlowToPngImage
+        for (int x = 0; x < plane_x.cols; ++x) {
+            o[3 * x] = px[x];
+            o[3 * x + 1] = py[x];
+            o[3 * x + 2] = b;
+        }
+    }
+    imencodePng(flow_img_bgr, encoded);
+}
+
 // ------------------------------------------------------------------------------------------------ writers
 
 static void write_blob(const string &file, const vector<uchar> &blob) {

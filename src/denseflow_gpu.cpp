@@ -32,6 +32,14 @@ static double trace_ms() {
         }                                                                                                       \
     } while (0)
 
+// adds the scope's wall time to a stage counter (DenseFlow::StageTimes)
+struct StageTick {
+    long long &acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit StageTick(long long &a) : acc(a) {}
+    ~StageTick() { acc += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 // ------------------------------------------------------------------------------------------------ queue
 
 static size_t flowbuffer_bytes(const FlowBuffer &b) {
@@ -111,6 +119,7 @@ DenseFlow::DenseFlow(vector<path> video_paths, vector<path> output_dirs, string 
       frames_gray_queue(3), flows_queue(3), total_frames(0), total_flows(0), dfx_(nullptr) {
     device_bounding = this->save_type == "jpg" && !std::getenv("DF_HOST_BOUND");
     device_jpeg = device_bounding && !std::getenv("DF_HOST_JPEG");
+    device_png = this->save_type == "png" && !std::getenv("DF_HOST_PNG");
     device_resize = !std::getenv("DF_HOST_RESIZE");
     join_short_ = !std::getenv("DF_NO_JOIN");
     // short clips: let a few of them queue up so that the flow stage can join them (large FlowBuffers stay at 3 per queue)
@@ -274,7 +283,11 @@ int DenseFlow::load_frames_video(VideoCapture &video_stream, vector<path> &frame
     vector<Mat> padding;
     while (true) {
         vector<Mat> frames_gray;
-        const bool is_open = load_frames_batch(video_stream, frames_path, use_frames, frames_gray, do_resize, size, true);
+        bool is_open;
+        {
+            StageTick tick(stage_us.load_read);
+            is_open = load_frames_batch(video_stream, frames_path, use_frames, frames_gray, do_resize, size, true);
+        }
         vector<Mat> padded(padding);
         padded.insert(padded.end(), frames_gray.begin(), frames_gray.end());
         if (verbose)
@@ -282,9 +295,12 @@ int DenseFlow::load_frames_video(VideoCapture &video_stream, vector<path> &frame
                  << endl;
         TRACE("load: push %zu frames, base %d, last_buffer %d, final %d", padded.size(), video_flow_idx, (int)!is_open,
               (int)(is_last && !is_open));
-        frames_gray_queue.push(FlowBuffer(padded, output_dir, video_flow_idx, !is_open, false,
-                                          (do_resize && device_resize) ? size : Size()),
-                               is_last && !is_open);
+        {
+            StageTick tick(stage_us.load_push);
+            frames_gray_queue.push(FlowBuffer(padded, output_dir, video_flow_idx, !is_open, false,
+                                              (do_resize && device_resize) ? size : Size()),
+                                   is_last && !is_open);
+        }
         // the last |step| frames are needed again as the head of the next buffer (:204-207)
         padding.assign(padded.end() - std::min<size_t>(astep, padded.size()), padded.end());
         const int M = (int)padded.size() - astep;
@@ -352,7 +368,7 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
         // do not change any flow (the last |step| frames are carried over, :204-207).
         const long long frame_px = std::max((long long)size.width * size.height, (long long)src_w_ * src_h_);
         // (float flows — png / h5 / host-side bounding — are 8 bytes per pixel of page-locked output per pair: one batch)
-        const long long budget = device_bounding ? (512ll << 20) : (256ll << 20);
+        const long long budget = (device_bounding || device_png) ? (512ll << 20) : (256ll << 20);
         batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, budget / std::max(1ll, frame_px)));
         first_buffer_ = frame_px * batch_maxsize > (128ll << 20); // only where reading a full buffer takes a while
         if (const char *bm = std::getenv("DF_BATCH_MAXSIZE")) // testing aid: force short buffers
@@ -398,7 +414,12 @@ void DenseFlow::collect_flows() {
             unique_lock<mutex> lock(pending_mtx_);
             failed = !pending_error_.empty();
         }
-        if (p->ticket && p->handle && dfx_wait(p->handle, p->ticket) != DFX_OK && !failed) {
+        int wrc = DFX_OK;
+        if (p->ticket && p->handle) {
+            StageTick tick(stage_us.collect_wait);
+            wrc = dfx_wait(p->handle, p->ticket);
+        }
+        if (wrc != DFX_OK && !failed) {
             const string msg = dfx_last_error(p->handle);
             unique_lock<mutex> lock(pending_mtx_);
             pending_error_ = msg.empty() ? string("dfx_wait failed") : msg;
@@ -420,6 +441,7 @@ void DenseFlow::collect_flows() {
                     std::copy(p->size_y.begin() + off, p->size_y.begin() + off + m, fb.encoded->size_y.begin());
                     off += m;
                 }
+            StageTick tick(stage_us.collect_push);
             for (size_t g = 0; g < p->flows.size(); ++g)
                 flows_queue.push(std::move(p->flows[g]), fin && g + 1 == p->flows.size());
         }
@@ -513,6 +535,7 @@ void DenseFlow::submit_group(vector<FlowBuffer> &group, const string &algorithm,
     pend->is_final = is_final;
     vector<vector<Mat>> flows(group.size());
     vector<std::shared_ptr<FlowBuffer::Encoded>> encoded(group.size());
+    vector<vector<double>> png_bounds(group.size());
     if (M > 0) {
         const Size in_sz = first->size();
         Size target;
@@ -578,6 +601,31 @@ void DenseFlow::submit_group(vector<FlowBuffer> &group, const string &algorithm,
             }
         }
         if (encoded_on_device) {
+        } else if (device_png) {
+            // convertFlowToPngImage's arithmetic (src/common.cpp:18-46) happens on the device: two 8-bit planes scaled by
+            // the flow's own adaptive bounds come back with those bounds — 2 bytes per pixel instead of 8
+            vector<uint8_t *> out_x, out_y;
+            size_t out_step = 0;
+            for (size_t g = 0; g < group.size(); ++g) {
+                flows[g].resize(2 * (size_t)m_of[g]);
+                for (int i = 0; i < m_of[g]; ++i) {
+                    flows[g][2 * i].create(sz, CV_8UC1);
+                    flows[g][2 * i + 1].create(sz, CV_8UC1);
+                    out_x.push_back(flows[g][2 * i].ptr<uint8_t>());
+                    out_y.push_back(flows[g][2 * i + 1].ptr<uint8_t>());
+                    out_step = flows[g][2 * i].step;
+                }
+            }
+            vector<double> all(2 * (size_t)M, 0.0); // complete when the submit call returns (include/dfx.h)
+            declare();
+            if (dfx_submit_batch_png(dfx_, in.data(), first->step, N, step, out_x.data(), out_y.data(), out_step, all.data(),
+                                     &ticket) != DFX_OK)
+                throw std::runtime_error(dfx_last_error(dfx_));
+            size_t off = 0;
+            for (size_t g = 0; g < group.size(); ++g) {
+                png_bounds[g].assign(all.begin() + off, all.begin() + off + 2 * (size_t)m_of[g]);
+                off += 2 * (size_t)m_of[g];
+            }
         } else if (device_bounding) {
             // encodeFlowMap's convertFlowToImage(-bound, bound) (src/common.cpp:52) happens on the device:
             // two 8-bit planes per flow come back instead of a float field
@@ -623,8 +671,9 @@ void DenseFlow::submit_group(vector<FlowBuffer> &group, const string &algorithm,
     // while this thread already submits the next FlowBuffer
     for (size_t g = 0; g < group.size(); ++g) {
         FlowBuffer result(std::move(flows[g]), group[g].output_dir, group[g].base_start, group[g].last_buffer,
-                          device_bounding && m_of[g] > 0);
+                          (device_bounding || device_png) && m_of[g] > 0);
         result.encoded = encoded[g];
+        result.png_bounds = std::move(png_bounds[g]);
         pend->flows.push_back(std::move(result));
     }
     enqueue_pending(std::move(pend));
@@ -661,6 +710,7 @@ void DenseFlow::calc_optflows(bool verbose) {
                 is_final = carry->second;
                 carry.reset();
             } else {
+                StageTick tick(stage_us.flow_pop);
                 group.push_back(frames_gray_queue.pop(&is_final));
             }
             if (group[0].engine_hint.width > 0) { // the loader's early notice: allocate while it reads the first frames
@@ -690,7 +740,10 @@ void DenseFlow::calc_optflows(bool verbose) {
                 is_final = fin;
             }
             flows_final_ = is_final;
-            submit_group(group, algorithm, step, false);
+            {
+                StageTick tick(stage_us.flow_submit);
+                submit_group(group, algorithm, step, false);
+            }
             if (is_final)
                 break;
         }
@@ -729,7 +782,11 @@ static void mark_done(const path &output_dir, bool has_class) {
 void DenseFlow::encode_save(string save_type, bool verbose) {
     while (true) {
         bool is_final = false;
-        FlowBuffer flow_buffer = flows_queue.pop(&is_final);
+        FlowBuffer flow_buffer = [&] {
+            StageTick tick(stage_us.save_pop);
+            return flows_queue.pop(&is_final);
+        }();
+        StageTick work_tick(stage_us.save_work);
         const int M = flow_buffer.encoded ? (int)flow_buffer.encoded->x.size()
                                           : (int)flow_buffer.item_data.size() / (flow_buffer.bounded ? 2 : 1);
         TRACE("save: %d flows, base %d, final %d", M, flow_buffer.base_start, (int)is_final);
@@ -767,11 +824,18 @@ void DenseFlow::encode_save(string save_type, bool verbose) {
             TRACE("save: written");
         } else if (save_type == "png") {
             vector<vector<uchar>> output(M);
-            parallelFor(M, encode_threads, [&](int i) {
-                Mat planes[2];
-                split(flow_buffer.item_data[i], planes);
-                encodeFlowMapPng(planes[0], planes[1], output[i]);
-            });
+            if (flow_buffer.bounded) { // the scheme's planes and bounds arrive from the device: interleave + encode only
+                parallelFor(M, encode_threads, [&](int i) {
+                    encodeFlowMapPngPlanes(flow_buffer.item_data[2 * i], flow_buffer.item_data[2 * i + 1],
+                                           flow_buffer.png_bounds[2 * i], flow_buffer.png_bounds[2 * i + 1], output[i]);
+                });
+            } else {
+                parallelFor(M, encode_threads, [&](int i) {
+                    Mat planes[2];
+                    split(flow_buffer.item_data[i], planes);
+                    encodeFlowMapPng(planes[0], planes[1], output[i]);
+                });
+            }
             writeFlowImagesPng(output, (flow_buffer.output_dir / "flow").string(), step, flow_buffer.base_start);
         } else if (save_type == "h5") { // unbounded float planes (reference :429-441)
             vector<Mat> output_h5_x(M), output_h5_y(M);
@@ -875,6 +939,15 @@ void DenseFlow::launch(bool use_frames, string save_type, bool verbose) {
     TRACE("launch: calc joined");
     t_save.join();
     TRACE("launch: save joined");
+    if (g_trace || std::getenv("DF_STAGES")) { // where each stage's wall time went (one line per pipeline)
+        const StageTimes &t = stage_us;
+        fprintf(stderr,
+                "[denseflow stages, device %d, ms] load: read %.0f / blocked on the frames queue %.0f | flow: waiting for "
+                "frames %.0f / in the library %.0f | collect: dfx_wait %.0f / blocked on the flows queue %.0f | save: waiting "
+                "for flows %.0f / encode + write %.0f\n",
+                device, t.load_read / 1e3, t.load_push / 1e3, t.flow_pop / 1e3, t.flow_submit / 1e3, t.collect_wait / 1e3,
+                t.collect_push / 1e3, t.save_pop / 1e3, t.save_work / 1e3);
+    }
     for (auto &e : err)
         if (e)
             std::rethrow_exception(e);
@@ -884,6 +957,7 @@ vector<Mat> DenseFlowTestAccess::run_calc_optflows_imp(DenseFlow &d, const vecto
                                                         const string &algorithm, int step, bool bounded) {
     d.device_bounding = bounded;
     d.device_jpeg = false; // this probe returns flows / bounded planes; the encoded form is tested through the CLI
+    d.device_png = false;
     d.flows_final_ = true;
     thread collector([&d] { d.collect_flows(); });
     std::exception_ptr err;

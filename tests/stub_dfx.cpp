@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <dlfcn.h>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <chrono>
 #include <mutex>
@@ -220,6 +221,48 @@ int dfx_submit_batch_u8(dfx_handle h, const uint8_t *const *frames, size_t frame
             std::memcpy(img_y[i] + (size_t)y * img_pitch, py[i].ptr<uchar>(y), (size_t)h->W);
         }
     *ticket = px.size() ? h->next_ticket++ : 0;
+    return DFX_OK;
+}
+
+// the -st=png scheme of the fake: the oracle's restatement when one is loaded (STUB_ORACLE), else the same formulas inline
+int dfx_submit_batch_png(dfx_handle h, const uint8_t *const *frames, size_t frame_pitch, int n_frames, int step,
+                         uint8_t *const *img_x, uint8_t *const *img_y, size_t img_pitch, double *bounds_xy, uint64_t *ticket) {
+    Prepared p;
+    const int rc = prepare(h, frames, frame_pitch, n_frames, step, p);
+    if (rc != DFX_OK)
+        return rc;
+    typedef void (*png_fn)(const float *, int, int, uint8_t *, uint8_t *, double *, uint8_t *);
+    png_fn orc = h->oracle ? (png_fn)dlsym(h->oracle, "orc_flow_to_png_planes") : nullptr;
+    std::vector<float> uv((size_t)h->W * h->H * 2);
+    std::vector<uint8_t> x((size_t)h->W * h->H), y((size_t)h->W * h->H);
+    for (int i = 0; i < p.pairs.size(); ++i) {
+        fake_flow(h, p.frames[dfx_pair_a(p.pairs, i, step)].data(), p.frames[dfx_pair_b(p.pairs, i, step)].data(), uv.data(),
+                  (size_t)h->W * 2);
+        if (orc) {
+            orc(uv.data(), h->W, h->H, x.data(), y.data(), bounds_xy + 2 * i, nullptr);
+        } else {
+            double mx[2] = {0, 0};
+            for (size_t k = 0; k < x.size(); ++k)
+                for (int c = 0; c < 2; ++c)
+                    mx[c] = std::max(mx[c], (double)std::fabs(uv[2 * k + c]));
+            for (int c = 0; c < 2; ++c) {
+                double b = std::min(255. * 4, std::ceil((std::min<double>(c ? h->H : h->W, mx[c]) * 128. / 127.) / 4) * 4);
+                if ((int)b % 8 == 0)
+                    b += 4;
+                bounds_xy[2 * i + c] = b;
+                const float a = (float)(1. / ((1. / 128.) * b));
+                for (size_t k = 0; k < x.size(); ++k) {
+                    const float t = uv[2 * k + c] * a;
+                    (c ? y : x)[k] = (uint8_t)std::min(255L, std::max(0L, std::lrint((double)(t + 128.f))));
+                }
+            }
+        }
+        for (int r = 0; r < h->H; ++r) {
+            std::memcpy(img_x[i] + (size_t)r * img_pitch, x.data() + (size_t)r * h->W, (size_t)h->W);
+            std::memcpy(img_y[i] + (size_t)r * img_pitch, y.data() + (size_t)r * h->W, (size_t)h->W);
+        }
+    }
+    *ticket = p.pairs.size() ? h->next_ticket++ : 0;
     return DFX_OK;
 }
 

@@ -2,7 +2,7 @@
 
 The other 1080p parity tests run one pair or `max_batch=2`; the engines size their launches from the batch (Farneback's
 row segments: 216 rows x 5 at 129 pairs, 54 x 20 at 2; TVL1's grid.z and step groups; Brox's patch schedule), so the
-automatic batch of a 1080p FlowBuffer — 129 pairs for TVL1 / Farneback, 65 for Brox — is a configuration of its own.
+automatic batch of a 1080p FlowBuffer — 129 pairs (256 Mpx of frames) — is a configuration of its own.
 One FlowBuffer of batch + 1 frames through the device-resident entry point (the one bench.py times): the first, a middle
 and the LAST flow of the batch against the oracle, bit for bit, plus TVL1's executed iteration table of the last pair.
 
@@ -17,7 +17,7 @@ from denseflow_amd.synth import HardClip, SynthClip
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("algo,frames", [("tvl1", 130), ("farn", 130), ("brox", 66)])
+@pytest.mark.parametrize("algo,frames", [("tvl1", 130), ("farn", 130), ("brox", 130)])
 def test_full_automatic_batch_at_1080p_first_middle_last_flow(dfx, oracle, algo, frames):
     import torch
 

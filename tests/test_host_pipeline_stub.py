@@ -110,7 +110,7 @@ def test_every_file_is_the_right_pair_under_the_right_name(stub, harness, oracle
 
 
 @pytest.mark.parametrize("st,env", [("jpg", {}), ("jpg", {"DF_HOST_JPEG": "1"}), ("jpg", {"STUB_JPEG_UNSUPPORTED": "1"}),
-                                    ("jpg", {"DF_HOST_BOUND": "1"}), ("png", {}), ("h5", {})])
+                                    ("jpg", {"DF_HOST_BOUND": "1"}), ("png", {}), ("png", {"DF_HOST_PNG": "1"}), ("h5", {})])
 def test_a_list_of_short_clips_is_joined_without_changing_a_byte(stub, tmp_path, st, env):
     """The flow stage joins the queued FlowBuffers of one geometry into one library call; DF_NO_JOIN=1 does not.  Clips of
     unequal lengths, one without a pair, one of another size in the middle; every save type and every bounding / encoding
@@ -135,6 +135,24 @@ def test_a_list_of_short_clips_is_joined_without_changing_a_byte(stub, tmp_path,
         assert outs["joined"][f] == outs["single"][f], f
     if st == "jpg":
         assert sum(f.endswith(".jpg") for f in outs["joined"]) == 2 * sum(max(n - 2, 0) for _, _, n in shapes)
+
+
+@pytest.mark.parametrize("oracle_backed", [False, True])
+def test_png_files_do_not_depend_on_where_the_scheme_runs(stub, oracle, tmp_path, oracle_backed):
+    """-st=png: convertFlowToPngImage's arithmetic (src/common.cpp:18-46) on the "device" (dfx_submit_batch_png: two planes
+    + the adaptive bounds come back, the save stage interleaves and encodes) or on the host from float flows
+    (DF_HOST_PNG=1, the reference's place): the same files, byte for byte.  With the oracle as the fake's backend the
+    device side is oracle/quant_oracle.c's restatement (pinned to the reference's own lines), so this also holds the
+    host shell's own convertFlowToPngImage to the reference."""
+    write_y4m(tmp_path / "clip.y4m", SynthClip(96, 64, 17).frames(7))
+    env = {"STUB_ORACLE": os.path.join(ROOT, "oracle", "liboracle.so")} if oracle_backed else {}
+    outs = {}
+    for tag, extra in (("device", {}), ("host", {"DF_HOST_PNG": "1"})):
+        _run(stub, [tmp_path / "clip.y4m", "-o=" + str(tmp_path / tag), "-a=farn", "-s=1", "-st=png"], {**env, **extra})
+        outs[tag] = _files(tmp_path / tag)
+    assert outs["device"].keys() == outs["host"].keys() and len(outs["device"]) == 6
+    for f in outs["device"]:
+        assert outs["device"][f] == outs["host"][f], f
 
 
 def test_joining_really_happens_when_clips_are_waiting(stub, tmp_path):

@@ -374,6 +374,27 @@ def test_cli_list_of_short_clips_is_joined_without_changing_a_byte(built, tmp_pa
         assert outs["joined"][f] == outs["single"][f], f
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo,step,size", [("tvl1", 1, (96, 64)), ("farn", -2, (130, 71)), ("brox", 1, (64, 48))])
+def test_cli_png_files_do_not_depend_on_where_the_scheme_runs(built, tmp_path, algo, step, size):
+    """-st=png on the real library: convertFlowToPngImage's arithmetic (/root/reference/src/common.cpp:18-46) on the device
+    (dfx_submit_batch_png, the default: 2 bytes per pixel + the bounds come back) or on the host from the float flows
+    (DF_HOST_PNG=1, the reference's place, 8 bytes per pixel): the same .png files, byte for byte — including FlowBuffers
+    cut short (ragged batches)."""
+    w, h = size
+    n = 9
+    clip = tmp_path / "clip.y4m"
+    write_y4m(clip, SynthClip(w, h, 23).frames(n))
+    outs = {}
+    for tag, env in (("device", {}), ("device_cut", {"DF_BATCH_MAXSIZE": "4"}), ("host", {"DF_HOST_PNG": "1"})):
+        r = subprocess.run([built, str(clip), "-o=" + str(tmp_path / tag), "-a=" + algo, "-s=%d" % step, "-st=png"],
+                           capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = {p.name: p.read_bytes() for p in sorted((tmp_path / tag / "clip").iterdir())}
+    assert len(outs["device"]) == n - abs(step) and all(f.endswith(".png") for f in outs["device"])
+    assert outs["device"] == outs["host"] and outs["device_cut"] == outs["host"]
+
+
 def _write_pgm_dir(d, frames):
     d.mkdir(parents=True)
     for i, fr in enumerate(frames):

@@ -71,3 +71,54 @@ def test_oracle_equals_compiled_reference_on_fresh_inputs(oracle):
         assert np.array_equal(ox, rx) and np.array_equal(oy, ry), (lo, hi)
         nx, ny = NR.flow_to_u8(flow, lo, hi)
         assert np.array_equal(nx, rx) and np.array_equal(ny, ry), (lo, hi)
+
+
+# ---- the -st=png scheme: convertFlowToPngImage, /root/reference/src/common.cpp:18-46 --------------------------------
+from tests.golden.make_png_planes_golden import CASES as PNG_CASES, flow_with_extrema  # noqa: E402
+
+PNG_GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "png_planes_golden.npz")
+
+
+@pytest.mark.parametrize("case", PNG_CASES, ids=[c[0] for c in PNG_CASES])
+def test_png_scheme_oracle_equals_reference_golden(oracle, case):
+    """Pinned like the bounding above: the golden images were produced by the reference's own lines
+    (tests/golden/make_png_planes_golden.py: oracle/_ref/libref_png.so)."""
+    name = case[0]
+    g = np.load(PNG_GOLDEN)
+    x, y, (bx, by), bgr = oracle.flow_to_png_planes(g[name + "_flow"])
+    want = g[name + "_bgr"]
+    assert np.array_equal(bgr, want)
+    assert np.array_equal(x, want[..., 0]) and np.array_equal(y, want[..., 1])
+    h = want.shape[0]
+    assert int(want[0, 0, 2]) == min(255, int(np.rint(bx / 4))) and int(want[h - 1, 0, 2]) == min(255, int(np.rint(by / 4)))
+
+
+def test_png_scheme_bound_rule_known_answers(oracle):
+    """ceil((min(extent, max|v|) * 128 / 127) / 4) * 4, capped at 1020, + 4 when a multiple of 8."""
+    def bounds(w, h, mu, mv):
+        f = np.zeros((h, w, 2), np.float32)
+        f[0, 0, 0], f[h - 1, w - 1, 1] = -mu, mv
+        return oracle.flow_to_png_planes(f)[2]
+
+    assert bounds(64, 48, 0.0, 0.0) == (4.0, 4.0)          # 0 is a multiple of 8
+    assert bounds(64, 48, 3.2, 7.9) == (4.0, 12.0)          # 8 -> 12
+    assert bounds(64, 48, 15.5, 11.9) == (20.0, 12.0)       # 16 -> 20
+    assert bounds(40, 30, 500.0, 77.0) == (44.0, 36.0)      # min(w, .) = 40 -> 40.31 -> 44; min(h, .) = 30 -> 32 -> 36
+    assert bounds(2000, 2000, 1500.0, 1012.0) == (1020.0, 1020.0)  # the 255 * 4 cap (1020 % 8 == 4)
+
+
+def test_png_scheme_golden_inputs_are_reproducible():
+    g = np.load(PNG_GOLDEN)
+    for name, w, h, mu, mv, seed, neg in PNG_CASES:
+        assert np.array_equal(flow_with_extrema(w, h, mu, mv, seed, neg), g[name + "_flow"])
+
+
+def test_png_scheme_oracle_equals_compiled_reference_on_fresh_inputs(oracle):
+    if not oracle.ref_png_available():
+        pytest.skip("oracle/_ref/libref_png.so not built (needs /root/reference: make -C oracle ref)")
+    rng = np.random.default_rng(3)
+    for k in range(12):
+        w, h = int(rng.integers(1, 90)), int(rng.integers(1, 70))
+        flow = flow_with_extrema(w, h, float(rng.choice([0.0, 0.3, 7.9, 15.5, 31.7, 300.0])),
+                                 float(rng.choice([0.0, 1.0, 3.9, 23.6, 64.0])), 200 + k, bool(k & 1))
+        assert np.array_equal(oracle.flow_to_png_planes(flow)[3], oracle.ref_flow_to_png_image(flow)), (w, h, k)
