@@ -161,6 +161,7 @@ void free_jpeg(dfx_context *c) {
     for (int q = 0; q < 2; ++q) {
         dfx_free_dev(j.d_stream[q]);
         dfx_free_host(j.h_stream[q]);
+        j.h_capacity[q] = 0;
         dfx_free_host(j.h_info[q]);
         j.d_info[q] = nullptr;
     }
@@ -192,7 +193,11 @@ int ensure_jpeg(dfx_context *c, int pairs, int quality) {
     j.capacity = ((planes * (size_t)c->W * c->H / 2 + (64u << 10)) + 255) & ~(size_t)255;
     for (int p = 0; p < 2; ++p) {
         HIPCHK(c, hipMalloc(&j.d_stream[p], j.capacity));
-        HIPCHK(c, hipHostMalloc(&j.h_stream[p], j.capacity, hipHostMallocDefault));
+        // The page-locked landing buffer starts at 1 bit per pixel (flow planes code to ~0.3-0.5) and grows to what a batch
+        // really needs (ensure_jpeg_landing): pinning 4 bits per pixel twice was ~0.1 s of a 1080p handle's first call
+        // (profiles/round5/e2e/) for bytes that never arrive.
+        j.h_capacity[p] = (j.capacity / 4 + 255) & ~(size_t)255;
+        HIPCHK(c, hipHostMalloc(&j.h_stream[p], j.h_capacity[p], hipHostMallocDefault));
         HIPCHK(c, hipHostMalloc(&j.h_info[p], (2 + 2 * planes) * 8, hipHostMallocMapped));
         std::memset(j.h_info[p], 0, (2 + 2 * planes) * 8);
         HIPCHK(c, hipHostGetDevicePointer((void **)&j.d_info[p], j.h_info[p], 0));
@@ -236,8 +241,27 @@ int grow_jpeg_streams(dfx_context *c, unsigned long long need) {
         dfx_free_host(j.h_stream[p]);
         j.d_stream[p] = nd[p];
         j.h_stream[p] = nh[p];
+        j.h_capacity[p] = cap;
     }
     j.capacity = cap;
+    return DFX_OK;
+}
+
+// The landing buffer of parity q holds at least `need` bytes (the total a batch's scan pass measured).  Nothing reads or
+// writes h_stream[q] when this is called: the caller has finished the tails of that parity and its copy is not enqueued yet.
+int ensure_jpeg_landing(dfx_context *c, int q, size_t need) {
+    auto &j = c->jpeg;
+    if (need <= j.h_capacity[q])
+        return DFX_OK;
+    const size_t cap = std::min(j.capacity, ((need + need / 2) + 255) & ~(size_t)255);
+    unsigned char *nh = nullptr;
+    if (hipHostMalloc((void **)&nh, cap, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return dfx_fail(c, DFX_ERR_HIP, "growing the JPEG landing buffer failed");
+    }
+    dfx_free_host(j.h_stream[q]);
+    j.h_stream[q] = nh;
+    j.h_capacity[q] = cap;
     return DFX_OK;
 }
 
@@ -480,9 +504,13 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
                 return dfx_fail(c, DFX_ERR_UNSUPPORTED,
                                 "JPEG: the batch's streams do not fit the stream buffer (use the 8-bit plane output and encode "
                                 "on the host)");
-            if (jb[k].total > 0)
+            if (jb[k].total > 0) {
+                const int grc = ensure_jpeg_landing(c, q, (size_t)jb[k].total);
+                if (grc != DFX_OK)
+                    return grc;
                 HIPCHK(c, hipMemcpyAsync(c->jpeg.h_stream[q], c->jpeg.d_stream[q], (size_t)jb[k].total,
                                          hipMemcpyDeviceToHost, c->d2h_stream));
+            }
             HIPCHK(c, hipEventRecord(c->ev_d2h[q], c->d2h_stream));
             return DFX_OK;
         }
@@ -563,23 +591,14 @@ int calc_batch_body(dfx_context *c, const uint8_t *const *frames, size_t frame_p
         if (rc != DFX_OK)
             return rc;
     }
-    // helper thread for the host-side post-processing of the previous batch; joined on every path out of this function
-    struct Post {
-        std::thread th;
-        int rc = DFX_OK;
-        void start(std::function<int()> fn) {
-            (void)finish();
-            th = std::thread([this, fn] { rc = fn(); });
-        }
-        int finish() {
-            if (th.joinable())
-                th.join();
-            const int r = rc;
-            rc = DFX_OK;
-            return r;
-        }
-        ~Post() { (void)finish(); }
-    } post;
+    // the handle's helper thread runs the host-side post-processing of the previous batch; its job captures this
+    // function's locals by reference, so it is finished on every path out of here
+    struct PostGuard {
+        DfxHelper &h;
+        void start(std::function<int()> fn) { h.start(std::move(fn)); }
+        int finish() { return h.finish(); }
+        ~PostGuard() { (void)h.finish(); }
+    } post{c->helper};
     for (size_t k = 0; k < plan.size(); ++k) {
         const DfxBatchPlan &p = plan[k];
         if (host_mode) {
@@ -1287,6 +1306,11 @@ int dfx_encode_jpeg(dfx_handle h, const uint8_t *const *planes, size_t pitch, in
         if (hi[1])
             return dfx_fail(h, DFX_ERR_UNSUPPORTED,
                             "JPEG: the planes do not fit the stream buffer (encode them on the host)");
+        {
+            const int lrc = ensure_jpeg_landing(h, 0, (size_t)hi[0]); // synchronous entry point: no tail is in flight
+            if (lrc != DFX_OK)
+                return lrc;
+        }
         HIPCHK(h, hipMemcpyAsync(h->jpeg.h_stream[0], h->jpeg.d_stream[0], (size_t)hi[0], hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         for (int j = 0; j < nc; ++j) {

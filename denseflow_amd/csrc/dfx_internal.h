@@ -16,6 +16,7 @@
 
 #include "../../include/dfx.h"
 #include "dfx_device.h"
+#include "dfx_helper.h"
 
 // An algorithm engine owns every device buffer of one handle.  The common driver (dfx_api.cpp)
 // walks a FlowBuffer in batches of `batch()` pairs, keeps the per-frame derived data (pyramids,
@@ -107,11 +108,13 @@ struct dfx_context {
         unsigned long long *d_plane_bits = nullptr, *d_plane_base = nullptr;
         unsigned *d_stream[2] = {nullptr, nullptr};
         unsigned char *h_stream[2] = {nullptr, nullptr};
+        size_t h_capacity[2] = {0, 0}; // page-locked landing buffers: sized to what batches actually need (ensure_jpeg_landing)
         unsigned long long *h_info[2] = {nullptr, nullptr}, *d_info[2] = {nullptr, nullptr}; // mapped page-locked
         unsigned long long *d_hdr = nullptr; // device copy of (total, overflow): the emit pass must not poll host memory
         size_t capacity = 0;
         std::vector<unsigned char> header;
     } jpeg;
+    DfxHelper helper;              // host-side work beside the calling thread (dfx_helper.h): one thread per handle
     std::vector<int> h_slots;      // slot id of each new frame of the current batch
     std::vector<PairDesc> h_pairs; // descriptors of the current batch
 

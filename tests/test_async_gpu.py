@@ -51,3 +51,43 @@ def test_empty_flowbuffer_has_no_ticket(dfx):
         t, flows = eng.submit_optflows(SynthClip(64, 48, 1).frames(1), 1)
         assert t == 0 and flows == []
         eng.wait(0)
+
+
+def test_one_helper_thread_per_handle_across_many_batches_and_calls(dfx):
+    """the host-side work beside the calling thread (hand-over from the bounce buffer, JPEG assembly, the
+    gather of the next batch's small frames) runs on ONE persistent thread per handle (dfx_helper.h) instead of a
+    std::thread per batch.  Small frames (bounce buffers in both directions), max_batch = 2 -> 6 batches per FlowBuffer,
+    every output kind, repeated calls on one handle and two handles side by side: the results of the one-batch handle."""
+    import threading
+
+    w, h, n = 112, 80, 13
+    frames = SynthClip(w, h, 33).frames(n)
+    with dfx.FlowEngine(w, h, "farn") as one:
+        ref_f = one.calc_optflows(frames, 1)
+        ref_x, ref_y = one.calc_optflows_u8(frames, 1, 20)
+        ref_jx, ref_jy = one.calc_optflows_jpeg(frames, 1, 20)
+        ref_px, ref_py, ref_b = one.calc_optflows_png(frames, 1)
+
+    def work(errors):
+        try:
+            with dfx.FlowEngine(w, h, "farn", max_batch=2) as eng:
+                for _ in range(3):  # the same thread serves every call of the handle
+                    f = eng.calc_optflows(frames, 1)
+                    x, y = eng.calc_optflows_u8(frames, 1, 20)
+                    jx, jy = eng.calc_optflows_jpeg(frames, 1, 20)
+                    px, py, b = eng.calc_optflows_png(frames, 1, submit=True)
+                    assert all(np.array_equal(a, r) for a, r in zip(f, ref_f))
+                    assert all(np.array_equal(a, r) for a, r in zip(x, ref_x)) and all(np.array_equal(a, r) for a, r in zip(y, ref_y))
+                    assert jx == ref_jx and jy == ref_jy
+                    assert all(np.array_equal(a, r) for a, r in zip(px, ref_px)) and np.array_equal(b, ref_b)
+                    assert all(np.array_equal(a, r) for a, r in zip(py, ref_py))
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    errors = []
+    threads = [threading.Thread(target=work, args=(errors,)) for _ in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

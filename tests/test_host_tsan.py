@@ -134,3 +134,22 @@ def test_whole_pipeline_under_address_and_undefined_behaviour_sanitizers(tmp_pat
     r = subprocess.run([exe, str(pg), "--if", "-o=" + str(tmp_path / "badp"), "-a=farn", "-s=1"], capture_output=True,
                        text=True, timeout=60, env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0"})
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+
+
+def test_the_library_helper_thread_is_race_free_under_tsan(tmp_path):
+    """denseflow_amd/csrc/dfx_helper.h — the one persistent helper thread of a handle (it used to be a
+    std::thread per batch) — under ThreadSanitizer, driven the way calc_batch_body's host-pointer path drives it with
+    bounce buffers and device JPEG over 3 … 11 batches: hand-over of batch k-1 and gather of batch k+1 beside the owner's
+    batch k, finish() before every reuse, a failing job, destruction with a job in flight."""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "helper_tsan")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", os.path.join(ROOT, "tests", "helper_tsan.cpp"),
+                        "-lpthread", "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and ("tsan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("ThreadSanitizer build not available here: " + r.stderr[-300:])
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, env={**os.environ, "TSAN_OPTIONS": "halt_on_error=0"})
+    assert r.stdout.startswith("bad 0 "), r.stdout + r.stderr[-2000:]
+    assert "WARNING: ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.returncode == 0
