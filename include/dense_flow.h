@@ -115,7 +115,7 @@ class DenseFlow {
     bool device_resize;
 
     int batch_maxsize;
-    bool first_buffer_ = false; // the next FlowBuffer is the first of its video: a quarter of batch_maxsize
+    int ramp_buffers_ = 0; // the next FlowBuffers of a video with large frames: 2 -> a quarter, 1 -> half of batch_maxsize
     // Level-2 sharding: this pipeline computes flows [begin, end) of every video, the contiguous
     // range of shard `shard_rank` of `shard_world`; output indices stay global through base_start.  Frames
     // [begin, end + |step|) are loaded — the |step| overlap frames the reference's own batch padding duplicates

@@ -241,8 +241,13 @@ bool DenseFlow::load_frames_batch(VideoCapture &video_stream, const vector<path>
                                   vector<Mat> &frames_gray, bool do_resize, const Size &size, bool to_gray) {
     // to_gray: the flow pipeline (sources are gray already: Y plane / PGM / BGR2GRAY in imreadGray); false: -s=0
     int cnt = 0;
-    const int limit = first_buffer_ ? std::max(std::min(32, batch_maxsize), batch_maxsize / 4) : batch_maxsize;
-    first_buffer_ = false;
+    // A video with large frames starts with a quarter buffer, then a half one: the GPU begins after 64 frames instead
+    // of 258 and is not left waiting for the first full buffer (the loader is only ~15 % faster than Farneback at 1080p:
+    // profiles/round5/e2e/).  Buffer boundaries do not change any flow.
+    const int limit = ramp_buffers_ > 0 ? std::max(std::min(32, batch_maxsize), batch_maxsize / (ramp_buffers_ == 2 ? 4 : 2))
+                                        : batch_maxsize;
+    if (ramp_buffers_ > 0)
+        --ramp_buffers_;
     while (cnt < limit) {
         Mat frame;
         if (frames_budget == 0) // this pipeline's shard of the video ends here
@@ -364,13 +369,14 @@ void DenseFlow::load_frames(bool use_frames, string save_type, bool verbose) {
         // TWO FULL device batches (the engine advances min(512, 256 Mi / pixels) pairs together: 129 at 1080p, where a
         // batch of 64 runs 4 % slower): 258 frames at 1080p, 512 from 1024x1024 down — with -st=jpg the results are JPEG
         // files or 8-bit planes, so a buffer's memory is its frames.  The three stages only overlap across buffers, so the
-        // FIRST buffer of a video is a quarter of that (the GPU starts after 64 frames, not 258).  Buffer boundaries
-        // do not change any flow (the last |step| frames are carried over, :204-207).
+        // FIRST buffer of a video is a quarter of that and the second a half (the GPU starts after 64 frames, not 258, and
+        // does not run dry while the first full buffer is read).  Buffer boundaries do not change any flow (the last |step|
+        // frames are carried over, :204-207).
         const long long frame_px = std::max((long long)size.width * size.height, (long long)src_w_ * src_h_);
         // (float flows — png / h5 / host-side bounding — are 8 bytes per pixel of page-locked output per pair: one batch)
         const long long budget = (device_bounding || device_png) ? (512ll << 20) : (256ll << 20);
         batch_maxsize = (int)std::max<long long>(32, std::min<long long>(512, budget / std::max(1ll, frame_px)));
-        first_buffer_ = frame_px * batch_maxsize > (128ll << 20); // only where reading a full buffer takes a while
+        ramp_buffers_ = frame_px * batch_maxsize > (128ll << 20) ? 2 : 0; // only where reading a full buffer takes a while
         if (const char *bm = std::getenv("DF_BATCH_MAXSIZE")) // testing aid: force short buffers
             batch_maxsize = std::max(1, std::atoi(bm));
         if (verbose)
