@@ -16,6 +16,9 @@
 
 #include "utils.h"
 
+#include <sys/wait.h>
+#include <unistd.h>
+
 // DF_TRACE=1: stage-by-stage trace on stderr (debugging aid; the reference has none)
 static const bool g_trace = std::getenv("DF_TRACE") != nullptr;
 static double trace_ms() {
@@ -1020,6 +1023,61 @@ void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_di
         workers.back()->set_blocking_waits(G > 1);
     }
     const double start_t = CurrentSeconds();
+    // DF_PROCESSES=1: one PROCESS per pipeline instead of one thread set (Level 1 / Level 2 sharding unchanged).  Two
+    // processes on ONE device (DF_DEVICES=0,0) overlap their launch gaps and host phases where two handles of one process
+    // share a HIP runtime and do not (round 2: 403 -> 430 pairs/s for TVL1 at 1080p); it is also the rehearsal of an
+    // N-rank launch on a one-GPU box.  The parent must not have touched HIP before the fork (tools/denseflow.cpp takes the
+    // device list from DF_DEVICES then), builds nothing itself and only adds up the children's counts.
+    static const bool use_processes = std::getenv("DF_PROCESSES") != nullptr;
+    unsigned long N = 0, F = 0;
+    if (use_processes && G > 1) {
+        std::cout.flush();
+        std::cerr.flush();
+        vector<pid_t> pids(G);
+        vector<int> fds(G);
+        for (size_t g = 0; g < G; ++g) {
+            int pp[2];
+            if (pipe(pp) != 0)
+                throw std::runtime_error("pipe() failed");
+            const pid_t pid = fork();
+            if (pid < 0)
+                throw std::runtime_error("fork() failed");
+            if (pid == 0) { // child: its own pipeline, its own HIP runtime
+                close(pp[0]);
+                int rc = 0;
+                try {
+                    if (step == 0)
+                        workers[g]->extract_frames_only(use_frames, verbose);
+                    else
+                        workers[g]->launch(use_frames, save_type, verbose);
+                    const unsigned long cnt[2] = {workers[g]->get_processed_total_frames(), workers[g]->get_processed_total_flows()};
+                    if (write(pp[1], cnt, sizeof cnt) != (ssize_t)sizeof cnt)
+                        rc = 1;
+                } catch (const std::exception &ex) {
+                    cout << ex.what() << endl;
+                    rc = 1;
+                }
+                std::cout.flush();
+                std::cerr.flush();
+                _exit(rc); // no destructors of the parent's copies, no atexit handlers of a runtime this process did not start
+            }
+            close(pp[1]);
+            pids[g] = pid, fds[g] = pp[0];
+        }
+        bool failed = false;
+        for (size_t g = 0; g < G; ++g) {
+            unsigned long cnt[2] = {0, 0};
+            const bool got = read(fds[g], cnt, sizeof cnt) == (ssize_t)sizeof cnt;
+            close(fds[g]);
+            int status = 0;
+            waitpid(pids[g], &status, 0);
+            if (!got || !WIFEXITED(status) || WEXITSTATUS(status) != 0)
+                failed = true;
+            N += cnt[0], F += cnt[1];
+        }
+        if (failed)
+            throw std::runtime_error("a pipeline process failed (its message is above)");
+    } else {
     vector<std::exception_ptr> errs(G);
     vector<thread> threads;
     for (size_t g = 0; g < G; ++g)
@@ -1038,14 +1096,14 @@ void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_di
     for (auto &e : errs)
         if (e)
             std::rethrow_exception(e);
-    if (split && is_record)
-        for (const path &od : output_dirs)
-            mark_done(od, has_class);
-    const double end_t = CurrentSeconds();
-    unsigned long N = 0, F = 0;
     for (auto &w : workers) {
         N += w->get_processed_total_frames(); // split: the |step| overlap frames are counted by every shard
         F += w->get_processed_total_flows();
     }
+    }
+    if (split && is_record)
+        for (const path &od : output_dirs)
+            mark_done(od, has_class);
+    const double end_t = CurrentSeconds();
     print_summary(video_paths.size(), N, F, algorithm, std::max(end_t - start_t, 1e-3));
 }

@@ -197,6 +197,32 @@ def test_flowbuffer_boundaries_and_device_pipelines_do_not_change_the_files(stub
     assert _files(tmp_path / "split") == one
 
 
+@pytest.mark.parametrize("what", ["one clip split by pair ranges", "a list dealt round-robin"])
+def test_pipelines_as_processes_write_the_same_files(stub, tmp_path, what):
+    """DF_PROCESSES=1: every device pipeline is a PROCESS (fork before any library call) instead of a thread set — Level 2
+    (one clip, contiguous pair ranges) and Level 1 (a list) — and the parent adds up the children's counts for the
+    reference's summary line.  Same files as one pipeline; a failing child ends the run with a non-zero status."""
+    if what.startswith("one"):
+        write_y4m(tmp_path / "clip.y4m", SynthClip(64, 48, 3).frames(11))
+        src, n_frames, n_flows = tmp_path / "clip.y4m", 11, 10
+    else:
+        lines = []
+        for i in range(5):
+            write_y4m(tmp_path / f"c{i}.y4m", SynthClip(64, 48, 60 + i).frames(6 + i))
+            lines.append(str(tmp_path / f"c{i}.y4m"))
+        (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
+        src, n_frames, n_flows = tmp_path / "list.txt", sum(6 + i for i in range(5)), sum(5 + i for i in range(5))
+    outs = {}
+    for tag, env in (("one", {}), ("threads", {"DF_DEVICES": "0,0,0"}), ("procs", {"DF_DEVICES": "0,0,0", "DF_PROCESSES": "1"})):
+        r = _run(stub, [src, "-o=" + str(tmp_path / tag), "-a=farn", "-s=1", "-b=20"], env)
+        outs[tag] = {k: v for k, v in _files(tmp_path / tag).items() if ".done" not in k}
+        assert f"{n_flows} farn flows) processed" in r.stdout, r.stdout
+    assert outs["one"] and outs["threads"] == outs["one"] and outs["procs"] == outs["one"]
+    r = subprocess.run([stub, str(src), "-o=" + str(tmp_path / "bad"), "-a=farn", "-s=1"], capture_output=True, text=True,
+                       env={**os.environ, "DF_DEVICES": "0,0", "DF_PROCESSES": "1", "STUB_FAIL_SUBMIT": "1"})
+    assert r.returncode != 0 and "a pipeline process failed" in r.stdout, r.stdout + r.stderr
+
+
 def test_a_list_sharded_over_device_pipelines_and_done_records(stub, tmp_path):
     """Level 1: the videos of a list are dealt to the device pipelines; the files and the .done records are those of one
     pipeline, and a second run skips every video that is marked done (no -f)."""

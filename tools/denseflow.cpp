@@ -194,7 +194,10 @@ int main(int argc, char **argv) {
         }
         if (!video_paths.empty()) {
             vector<int> devices;
-            const int avail = std::max(dfx_device_count(), 1);
+            // DF_PROCESSES=1 forks one process per pipeline: this process must not start the HIP runtime then, so the device
+            // list is taken from DF_DEVICES as it stands (each child fails with the library's message on a bad index)
+            const bool forked = std::getenv("DF_PROCESSES") && std::getenv("DF_DEVICES");
+            const int avail = forked ? (1 << 16) : std::max(dfx_device_count(), 1);
             for (int g = 0; g < std::max(1, std::min(gpus, avail)); ++g)
                 devices.push_back(g);
             if (const char *dl = std::getenv("DF_DEVICES")) { // explicit device list, e.g. "2,3" or (testing) "0,0"
