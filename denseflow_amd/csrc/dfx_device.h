@@ -67,6 +67,7 @@ struct Tvl1LevelCtx {
     volatile int *host_done_flag;   // pinned host word: set to done_token when every pair finished
     int done_token;
     int split_warp; // the backward warp runs as its own kernel in front of every step: the step kernel skips phase WARP
+    int warp_lds;   // that kernel gathers through an LDS tile (the default; 0 with DFX_VAR_TVL1_WARP_GATHER)
     int geom;       // tile geometry of the default step kernel: bit 0 = tile columns start at x = 0, bit 1 = halo as wide
                     // as the step is long (k_tvl1_step_fused; 0 = classic)
 };

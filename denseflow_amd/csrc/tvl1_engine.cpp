@@ -268,6 +268,7 @@ Tvl1LevelCtx Tvl1Engine::level_ctx(int s, int n_pairs) const {
     x.host_done_flag = d_done_flag;
     x.done_token = 0;
     x.split_warp = split_warp ? 1 : 0;
+    x.warp_lds = (c->prm.variant & DFX_VAR_TVL1_WARP_GATHER) ? 0 : 1;
     x.geom = geom;
     return x;
 }
