@@ -20,14 +20,39 @@
 
 static inline dim3 bgrid(int w, int h, int z) { return dim3((w + 63) / 64, (h + 3) / 4, z); }
 
-__device__ __forceinline__ int mirror_idx(int i, int n) { // edge-duplicating mirror, any offset
+__device__ __forceinline__ int mirror_idx_any(int i, int n) { // edge-duplicating mirror, any offset
     const int p = 2 * n;
     int m = i % p;
     if (m < 0)
         m += p;
     return m < n ? m : p - 1 - m;
 }
-__device__ __forceinline__ float inv_sqrtf_ieee(float s) { return 1.0f / sqrtf(s); }
+// The same for i in [-n, 2n) — one reflection: -1 - i (= ~i) below 0, 2n - 1 - i from n on.  Every index a flow smaller
+// than the image can produce is in that range; the general form's 32-bit `%` by a run-time divisor is ~35 VALU
+// instructions, and four of them per pixel were a third of stage 1's instruction count (round 5).
+__device__ __forceinline__ int mirror_idx_near(int i, int n) {
+    const int r = i ^ (i >> 31);
+    return r < n ? r : 2 * n - 1 - r;
+}
+__device__ __forceinline__ int mirror_idx(int i, int n) {
+    return __builtin_expect(i < -n || i >= 2 * n, 0) ? mirror_idx_any(i, n) : mirror_idx_near(i, n);
+}
+// 1.0f / sqrtf(s), both IEEE, for s in [2^-85, 2^127) (the callers add BROX_EPS2 = 1e-6 to a sum of squares): the square
+// root is the core sequence of tvl1_sqrt_scaled (correctly rounded for every float of that range: checked exhaustively on
+// the device, tests/test_device_math_gpu.py) without its scaling, the reciprocal the exact Newton division of tvl1_math.h
+// (checked against IEEE division over the Brox range of denominators) — 16 instructions instead of the compiler's ~27 for
+// the two library expansions with their range scaling and fix-ups.
+__device__ __forceinline__ float inv_sqrtf_ieee(float s) {
+    const float y = __builtin_amdgcn_rsqf(s);
+    float g = s * y;
+    float h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    h = __builtin_fmaf(h, r, h);
+    g = __builtin_fmaf(g, r, g);
+    const float d = __builtin_fmaf(-g, g, s);
+    g = __builtin_fmaf(d, h, g);
+    return tvl1_div(1.0f, g);
+}
 __device__ __forceinline__ float brox_bicubic_w(float x_) {
     const float x = fabsf(x_);
     const float near = x * x * (1.5f * x - 2.5f) + 1.0f;
@@ -100,8 +125,10 @@ __global__ __launch_bounds__(256) void k_brox_deriv(float *frames, long long fra
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const float v = axis == 0 ? src[(long long)y * pitch + mirror_idx(x + k - 2, w)]
-                                  : src[(long long)mirror_idx(y + k - 2, h) * pitch + x];
+        // taps at distance <= 2 of a pixel: inside [-n, 2n) whenever n >= 2 (a wave-uniform test; Brox levels are >= 16 px)
+        const int tx = x + k - 2, ty = y + k - 2;
+        const float v = axis == 0 ? src[(long long)y * pitch + (w >= 2 ? mirror_idx_near(tx, w) : mirror_idx_any(tx, w))]
+                                  : src[(long long)(h >= 2 ? mirror_idx_near(ty, h) : mirror_idx_any(ty, h)) * pitch + x];
         s = s + v * kD[k];
     }
     base[dst_off + (long long)y * pitch + x] = s * (1.0f / 12.0f);
@@ -135,8 +162,15 @@ __device__ __forceinline__ BlTap bl_setup(float fx, float fy, int w, int h, int 
     const float x0 = floorf(fx), y0 = floorf(fy);
     t.ax = fx - x0;
     t.ay = fy - y0;
-    const int xa = mirror_idx((int)x0, w), xb = mirror_idx((int)x0 + 1, w);
-    const int ya = mirror_idx((int)y0, h), yb = mirror_idx((int)y0 + 1, h);
+    const int ix = (int)x0, iy = (int)y0;
+    int xa, xb, ya, yb;
+    if (__builtin_expect(ix < -w || ix + 1 >= 2 * w || iy < -h || iy + 1 >= 2 * h, 0)) { // a flow larger than the image
+        xa = mirror_idx_any(ix, w), xb = mirror_idx_any(ix + 1, w);
+        ya = mirror_idx_any(iy, h), yb = mirror_idx_any(iy + 1, h);
+    } else { // one branch for the four indices
+        xa = mirror_idx_near(ix, w), xb = mirror_idx_near(ix + 1, w);
+        ya = mirror_idx_near(iy, h), yb = mirror_idx_near(iy + 1, h);
+    }
     t.i00 = (unsigned)(ya * pitch + xa);
     t.i01 = (unsigned)(ya * pitch + xb);
     t.i10 = (unsigned)(yb * pitch + xa);

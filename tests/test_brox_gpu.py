@@ -97,6 +97,18 @@ def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
             assert np.array_equal(simple.view(np.uint32), fused.view(np.uint32)), (w, h, solver)
 
 
+@pytest.mark.parametrize("w,h,seed,t0,t1", [(224, 224, 1, 0, 8), (80, 56, 21, 0, 2), (40, 33, 4, 0, 3)])
+def test_mirror_index_fast_path_and_its_fallback(dfx, oracle, w, h, seed, t0, t1):
+    """Round 5: stage 1's four mirror indices take ONE reflection when the bilinear window lies within one image size of
+    the frame (mirror_idx_near) and the general modulo form otherwise, and 1 / sqrtf is an exact 16-instruction sequence.
+    Large flows (an 8-frame jump), tiny pyramid levels: still the oracle's bits."""
+    clip = SynthClip(w, h, seed)
+    f0, f1 = clip.frame(t0), clip.frame(t1)
+    with dfx.FlowEngine(w, h, "brox", max_batch=2) as eng:
+        out = eng.calc(f0, f1)
+    assert np.array_equal(out, oracle.brox_calc(f0, f1))
+
+
 def test_config5_shape_4k_step2(dfx, oracle):
     """BASELINE config 5 at its stated frame size: 3840x2160, -a=brox -s=2 (reference call
     src/denseflow_gpu.cpp:303, :331-334 with the pair rule of :315-316).  Four frames through the FlowBuffer entry
