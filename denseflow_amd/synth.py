@@ -206,3 +206,86 @@ class HardClip:
             v = v + torch.randn((h, w), dtype=torch.float64, device=device, generator=gen) * self.NOISE_SIGMA
             out[i] = torch.clamp(torch.round(v), 0, 255).to(torch.uint8)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Content classes of real video (round 6): what load_frames_batch hands to alg->calc on Kinetics / UCF material
+# (/root/reference/src/denseflow_gpu.cpp:146-177, 327-334) and the sinusoid clips above never contain — exactly flat
+# regions (gradient == 0, rho == 0), clipped plateaus at 0 / 255, frames without any texture, unrelated frame pairs.
+CONTENT_CLASSES = ("letterbox", "pillarbox", "constant", "constant_step", "saturated", "fade", "cut", "cartoon",
+                   "static_noise")
+
+
+class ContentClip:
+    """A seeded clip of one content class; `frame(t)` is a (H, W) uint8 array like SynthClip.frame.
+
+    letterbox      moving texture between constant-0 bars at the top and bottom (H // 8 rows each)
+    pillarbox      the same with bars left and right (W // 8 columns each)
+    constant       every frame is the constant 93
+    constant_step  frame t is the constant 40 + 37 * t (clipped to 255): two flat frames of different value
+    saturated      moving texture with the gain raised until >= 20 % of frame 0 sits at 0 and >= 20 % at 255
+    fade           frame t = round(alpha_t * texture_t), alpha_t = max(0, 1 - t / 5): frame 5 (and later) is all black
+    cut            frame 0 from one clip, frames >= 1 from an unrelated one: pair (0, 1) is a hard cut
+    cartoon        moving piecewise-constant regions (5 gray values) separated by 1-pixel step edges
+    static_noise   one still texture plus independent N(0, 5.1^2) sensor noise (2 % of full scale) per frame
+    """
+
+    FADE_FRAMES = 5
+    BAR_FRACTION = 8
+
+    def __init__(self, width: int, height: int, seed: int, kind: str):
+        if kind not in CONTENT_CLASSES:
+            raise ValueError(f"unknown content class {kind!r}")
+        self.width, self.height, self.seed, self.kind = int(width), int(height), int(seed), kind
+        self.base = SynthClip(width, height, seed)
+        self.other = SynthClip(width, height, seed + 15487469) if kind == "cut" else None
+        self._sat = None
+
+    def _noise(self, t: int, sigma: float):
+        rng = np.random.default_rng([self.seed, 32452843, int(t)])
+        return rng.standard_normal((self.height, self.width)) * sigma
+
+    def _float_texture(self, clip: SynthClip, t: float):
+        scale, offset = clip._get_affine()
+        return clip._texture(*clip._coords(float(t))) * scale + offset
+
+    def frame(self, t: int) -> np.ndarray:
+        k, w, h = self.kind, self.width, self.height
+        if k == "constant":
+            return np.full((h, w), 93, np.uint8)
+        if k == "constant_step":
+            return np.full((h, w), min(40 + 37 * int(t), 255), np.uint8)
+        if k == "cut":
+            return (self.base if t < 1 else self.other).frame(t)
+        if k == "static_noise":
+            v = self._float_texture(self.base, 0.0) + self._noise(t, 0.02 * 255.0)
+            return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+        if k == "saturated":
+            if self._sat is None:  # gain / offset from frame 0: its 30th percentile -> 0, its 70th -> 255
+                lo, hi = np.percentile(self._float_texture(self.base, 0.0), [30.0, 70.0])
+                self._sat = (255.0 / (hi - lo), lo)
+            g, lo = self._sat
+            return np.clip(np.rint((self._float_texture(self.base, t) - lo) * g), 0, 255).astype(np.uint8)
+        if k == "fade":
+            a = max(0.0, 1.0 - float(t) / self.FADE_FRAMES)
+            return np.clip(np.rint(a * self._float_texture(self.base, t)), 0, 255).astype(np.uint8)
+        if k == "cartoon":
+            q = np.floor(self._float_texture(self.base, t) / 51.2)  # 5 regions over [0, 256)
+            return np.clip(q * 51.0 + 25.0, 0, 255).astype(np.uint8)
+        f = self.base.frame(t)
+        if k == "letterbox":
+            bar = max(1, h // self.BAR_FRACTION)
+            f[:bar, :] = 0
+            f[h - bar:, :] = 0
+        else:  # pillarbox
+            bar = max(1, w // self.BAR_FRACTION)
+            f[:, :bar] = 0
+            f[:, w - bar:] = 0
+        return f
+
+    def frames(self, n: int, start: int = 0):
+        return [self.frame(start + i) for i in range(n)]
+
+    def pairs(self):
+        """(t0, t1) frame pairs that exercise what the class is for."""
+        return {"fade": [(0, 1), (4, 5), (5, 6)], "constant_step": [(0, 1), (1, 0)]}.get(self.kind, [(0, 1)])
