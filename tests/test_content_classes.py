@@ -79,8 +79,10 @@ def test_brox_oracle_equals_numpy(oracle, kind, w, h, seed, which):
     flow = oracle.brox_calc(f0, f1)
     assert np.isfinite(flow).all()
     assert np.max(np.abs(flow - NR.brox_calc(f0, f1))) <= 1e-5  # tests/test_oracle_brox.py's bar
-    if kind in ("constant", "constant_step"):
+    if kind == "constant":
         assert not flow.any()
+    elif kind == "constant_step":  # the pyramid's bilinear weights do not sum to exactly 1: gradients of 1e-8 at coarse levels
+        assert np.abs(flow).max() < 1e-3
 
 
 @pytest.mark.parametrize("kind", ["constant", "constant_step", "fade"])

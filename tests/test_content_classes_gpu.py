@@ -161,5 +161,8 @@ def test_saved_outputs_of_a_flowbuffer(dfx, oracle, algo, kind):
             zero_flows += 1
             assert tuple(pb[i]) == (4.0, 4.0), what + ": the all-zero bound rule"
             assert (ux[i] == 128).all() and (uy[i] == 128).all()
-    if kind in ("constant", "constant_step") and algo != "farn":
-        assert zero_flows == n - 1  # flat frames: rho = 0 and grad = 0 everywhere -> the flow stays exactly zero
+    if kind == "constant" or (kind == "constant_step" and algo != "brox"):
+        # flat frames: no gradient anywhere -> the flow stays exactly zero.  (Brox on two flat frames of DIFFERENT value:
+        # its pyramid's bilinear weights do not sum to exactly 1, the coarse levels get gradients of 1e-8 and the flow a few
+        # 1e-5 px — the device reproduces even that bit for bit, checked above.)
+        assert zero_flows == n - 1
