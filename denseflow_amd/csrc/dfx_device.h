@@ -68,6 +68,9 @@ struct Tvl1LevelCtx {
     int done_token;
     int split_warp; // the backward warp runs as its own kernel in front of every step: the step kernel skips phase WARP
     int warp_lds;   // that kernel gathers through an LDS tile (the default; 0 with DFX_VAR_TVL1_WARP_GATHER)
+    int head;       // the warp kernel also runs the head of the loop it starts (k_tvl1_warp_head).  The dual planes of a level's
+                    // first warp are zero by definition (A.3): that kernel does not read them and k_tvl1_zero_planes does
+                    // not write them
     int geom;       // tile geometry of the default step kernel: bit 0 = tile columns start at x = 0, bit 1 = halo as wide
                     // as the step is long (k_tvl1_step_fused; 0 = classic)
 };

@@ -133,6 +133,47 @@ DFX_HD void tvl1_end_segment(Tvl1State &s, const Tvl1LoopCfg &c, const Tvl1StepP
 }
 
 // ------------------------------------------------------------------------------------------------
+// The warp-and-head kernel (k_tvl1_warp_head, tvl1_head_kernels.hip): the backward warp of a pair AND the head of the inner
+// loop it starts — its first TVL1_HEAD_ITERS iterations, which on converging content are the whole loop: the first
+// convergence check is due at iteration 1 (tvl1_next_check(0, ...)), and warps 1-4 of a level usually pass it — in ONE
+// launch, in front of the step kernel of the same step id.  I1wx / I1wy / rho_c go from the warp into the iterations in
+// registers.  These two functions are the state transitions of that launch; the CPU harness replays them
+// (tests/ctrl_harness.cpp, split_warp = 2).
+#define TVL1_HEAD_ITERS 2
+
+// The plan of the head, derived by every workgroup from the state as the pair's warp phase finds it (read-only: the state
+// changes once, in tvl1_end_head): what tvl1_begin_loop + tvl1_plan_step would plan for a first step of TVL1_HEAD_ITERS
+// iterations — iterations [0, min(TVL1_HEAD_ITERS, segment length)) reading set s.cur.  Requires c.iterations >= 1.
+DFX_HD Tvl1StepPlan tvl1_plan_head(const Tvl1State &s, const Tvl1LoopCfg &c) {
+    double pe = 0.0;
+    const int next_check = tvl1_next_check(0, c.iterations, s.thr, &pe);
+    const int end_n = next_check < c.iterations ? next_check : c.iterations - 1;
+    Tvl1StepPlan p;
+    p.n_first = 0;
+    const int last = TVL1_HEAD_ITERS - 1 < end_n ? TVL1_HEAD_ITERS - 1 : end_n;
+    p.n_iters = last + 1;
+    p.src = s.cur;
+    p.is_last = last == end_n;
+    p.do_check = p.is_last && end_n == next_check;
+    return p;
+}
+
+// The state transition of the launch (one thread, once every workgroup of the pair has arrived): the loop begins and its
+// head is accounted for.  Segment finished: exactly tvl1_end_segment, a further segment starting at THIS step id (the step
+// kernel follows in the stream).  Segment not finished (no check falls into the head: epsilon = 0): the same segment
+// goes on at iteration n_iters from the set the head wrote.
+DFX_HD void tvl1_end_head(Tvl1State &s, const Tvl1LoopCfg &c, const Tvl1StepPlan &p, int step_id, double error) {
+    tvl1_begin_loop(s, c, step_id - 1);
+    if (p.is_last) {
+        tvl1_end_segment(s, c, p, step_id - 1, error);
+    } else {
+        s.cur = p.src ^ 1;
+        s.seg_n0 = p.n_first + p.n_iters;
+        s.seg_step0 = step_id;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Tile geometry of a step of the default step kernel (k_tvl1_step_fused, 64 x 32 tiles with a K-pixel halo).
 //   shift = 1 (default): tile columns start at x = 0 instead of -K: the first tile also owns its left halo columns (the
 //               image border needs no halo) and the last one everything up to the right border — ceil((w - 2K) /

@@ -71,6 +71,7 @@ class Tvl1Engine final : public AlgoEngine {
     int group_override = 0;
     bool split_warp = false; // backward warp as its own kernel in front of every step (packed step kernels only)
     int geom = 0;            // 1 = tile columns of the step kernel start at x = 0 (Tvl1LevelCtx::geom)
+    bool warp_head = false;  // the warp kernel also runs the head of the loop it starts (k_tvl1_warp_head)
     int launched_steps[DFX_LVL_MAX] = {0};
 
     Tvl1LoopCfg loop{};
@@ -124,6 +125,8 @@ int Tvl1Engine::create() {
     split_warp = p.impl == 0 && p.tvl1_iterations > 0 && !(p.variant & DFX_VAR_TVL1_WARP_IN_STEP);
     // tile columns from x = 0 (tvl1_ctrl.h) need every warp outside the step kernel (its warp phase tiles classically)
     geom = (p.impl == 0 && split_warp && !(p.variant & DFX_VAR_TVL1_CLASSIC_GEOM)) ? 1 : 0;
+    // warp + head of the loop in one launch (round 6): the tuned forms only — every cross-check variant keeps its own kernels
+    warp_head = split_warp && geom == 1 && !(p.variant & (DFX_VAR_TVL1_NO_HEAD | DFX_VAR_TVL1_WARP_GATHER));
 
     // pyramid (A.2 step 3): cvRound(size*scaleStep) per level; a level below 16 px is discarded
     {
@@ -270,6 +273,7 @@ Tvl1LevelCtx Tvl1Engine::level_ctx(int s, int n_pairs) const {
     x.split_warp = split_warp ? 1 : 0;
     x.warp_lds = (c->prm.variant & DFX_VAR_TVL1_WARP_GATHER) ? 0 : 1;
     x.geom = geom;
+    x.head = warp_head ? 1 : 0;
     return x;
 }
 
@@ -295,7 +299,7 @@ int Tvl1Engine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
         Tvl1LevelCtx x = level_ctx(s, nb);
         x.done_token = ++done_token;
         tvl1_launch_level_begin(c->stream, x, s == nlevels - 1);
-        c->stats.kernel_launches += 2;
+        c->stats.kernel_launches += (warp_head && s != nlevels - 1) ? 1 : 2;
         launched_steps[s] = 0;
         if (loop.warps > 0) {
             const int G = steps_per_group(s, nb);
@@ -303,7 +307,9 @@ int Tvl1Engine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
             HIPCHK(c, hipEventRecord(ev_lvl[s][0], c->stream));
             for (int g = 0;; ++g) {
                 for (int i = 0; i < G; ++i) {
-                    if (split_warp)
+                    if (warp_head)
+                        tvl1_launch_warp_head(c->stream, x, step_id, math);
+                    else if (split_warp)
                         tvl1_launch_warp(c->stream, x, step_id);
                     tvl1_launch_step(c->stream, x, step_id++, impl, math);
                 }

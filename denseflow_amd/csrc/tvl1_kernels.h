@@ -16,6 +16,9 @@ void tvl1_launch_centered_gradient(hipStream_t s, const float *frame_I, float *f
                                    int h, int pitch);
 void tvl1_launch_level_begin(hipStream_t s, const Tvl1LevelCtx &c, int first_level);
 void tvl1_launch_warp(hipStream_t s, const Tvl1LevelCtx &c, int step_id); // dedicated backward-warp kernel of a step
+// the warp AND the head of the loop it starts (tvl1_head_kernels.hip), in place of tvl1_launch_warp
+void tvl1_launch_warp_head(hipStream_t s, const Tvl1LevelCtx &c, int step_id, int math);
+int tvl1_head_blocks(const Tvl1LevelCtx &c); // workgroups per pair of that launch
 void tvl1_launch_step(hipStream_t s, const Tvl1LevelCtx &c, int step_id, int impl, int math);
 int tvl1_step_blocks(const Tvl1LevelCtx &c, int impl); // workgroups per pair of a step launch
 int tvl1_fused_max_k();                                // largest supported inner-iteration fusion

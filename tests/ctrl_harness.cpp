@@ -10,7 +10,9 @@
 
 // split_warp = 0: a warp occupies a step of its own (the warp phase inside the step kernel);
 // split_warp = 1: the dedicated warp kernel runs in front of the step kernel of the SAME step id (k_tvl1_warp): the warp
-//                 starts the loop at this very step, and with zero iterations the step kernel skips the pair.
+//                 starts the loop at this very step, and with zero iterations the step kernel skips the pair;
+// split_warp = 2: that kernel also runs the head of the loop (k_tvl1_warp_head: tvl1_plan_head / tvl1_end_head); with
+//                 zero iterations the engine falls back to split_warp = 1, and so does this replay.
 extern "C" int ctrl_replay_level_ex(const float *I0, const float *I1, float *u1, float *u2, int W, int H, int warps,
                                     int iterations, int fuse_k, double eps, double lambda, double theta, double tau,
                                     int *iters_out, int *n_checks_out, int *steps_out, int split_warp);
@@ -42,7 +44,31 @@ extern "C" int ctrl_replay_level_ex(const float *I0, const float *I1, float *u1,
     int step_id = 0;
     const int limit = warps * (iterations + 2) + 64;
     for (; st.phase != TVL1_PH_LEVEL_DONE && step_id < limit; ++step_id) {
-        if (st.phase == TVL1_PH_WARP) {
+        if (st.phase == TVL1_PH_WARP && split_warp == 2 && iterations >= 1) {
+            orc_tvl1_warp_backward(I0, I1, I1x, I1y, u1, u2, W, H, I1w, I1wx, I1wy, grad, rho);
+            const Tvl1StepPlan hp = tvl1_plan_head(st, cfg);
+            { // the read-only plan is what begin_loop + plan_step plan for a first step of TVL1_HEAD_ITERS iterations
+                Tvl1State t = st;
+                Tvl1LoopCfg hc = cfg;
+                hc.fuse_k = TVL1_HEAD_ITERS;
+                tvl1_begin_loop(t, hc, step_id - 1);
+                const Tvl1StepPlan q = tvl1_plan_step(t, hc, step_id);
+                if (q.n_first != hp.n_first || q.n_iters != hp.n_iters || q.src != hp.src || q.is_last != hp.is_last ||
+                    q.do_check != hp.do_check)
+                    return -3;
+            }
+            if (hp.n_iters <= 0 || hp.n_iters > TVL1_HEAD_ITERS)
+                return -4;
+            double herr = 0.0;
+            for (int k = 0; k < hp.n_iters; ++k) {
+                const int check = hp.do_check && (k == hp.n_iters - 1);
+                herr = orc_tvl1_estimate_u(I1wx, I1wy, grad, rho, p11, p12, p21, p22, u1, u2, W, H, l_t, th, check);
+                orc_tvl1_estimate_dual(u1, u2, p11, p12, p21, p22, W, H, taut);
+            }
+            tvl1_end_head(st, cfg, hp, step_id, herr);
+            if (st.phase != TVL1_PH_ITER)
+                continue; // the step kernel of this step id skips pairs that are not iterating
+        } else if (st.phase == TVL1_PH_WARP) {
             orc_tvl1_warp_backward(I0, I1, I1x, I1y, u1, u2, W, H, I1w, I1wx, I1wy, grad, rho);
             tvl1_begin_loop(st, cfg, split_warp ? step_id - 1 : step_id);
             if (!split_warp || st.phase != TVL1_PH_ITER)

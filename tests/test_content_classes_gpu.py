@@ -66,13 +66,15 @@ def test_tvl1_every_kernel_form(dfx, oracle, kind, w, h):
 
 @pytest.mark.parametrize("kind", FLAT)
 def test_tvl1_warp_forms_and_tile_geometries_on_flat_content(dfx, oracle, kind):
-    """The cross-check forms of the tuned kernel (gather warp, warp inside the step kernel, classic tile geometry) and a
+    """The cross-check forms of the tuned kernel (warp and loop head as two launches, gather warp, warp inside the step
+    kernel, classic tile geometry) and a
     batch of pairs advancing together (different pairs of one batch converge at different steps)."""
     w, h = 224, 224
     clip = ContentClip(w, h, 11, kind)
     frames = clip.frames(7)
     refs = [oracle.tvl1_calc(frames[i], frames[i + 1]) for i in range(6)]
-    for variant in (0, dfx.engine.VAR_TVL1_WARP_GATHER, dfx.engine.VAR_TVL1_WARP_IN_STEP, dfx.engine.VAR_TVL1_CLASSIC_GEOM):
+    for variant in (0, dfx.engine.VAR_TVL1_NO_HEAD, dfx.engine.VAR_TVL1_WARP_GATHER, dfx.engine.VAR_TVL1_WARP_IN_STEP,
+                    dfx.engine.VAR_TVL1_CLASSIC_GEOM):
         with dfx.FlowEngine(w, h, "tvl1", variant=variant, max_batch=4) as eng:
             flows = eng.calc_optflows(frames, 1)
         for i in range(6):

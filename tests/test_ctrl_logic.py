@@ -42,14 +42,18 @@ def _level_inputs(w, h, seed, dt):
     return clip.frame(0).astype(np.float32), clip.frame(dt).astype(np.float32)
 
 
-@pytest.mark.parametrize("split_warp", [0, 1])
+@pytest.mark.parametrize("split_warp", [0, 1, 2])
 @pytest.mark.parametrize("fuse_k", [1, 2, 3, 4, 8, 16])
 @pytest.mark.parametrize("w,h,seed,dt,iterations", [(48, 40, 2, 1, 300), (40, 32, 4, 3, 300), (40, 32, 4, 3, 37),
                                                     (40, 32, 4, 1, 1), (40, 32, 4, 1, 2), (40, 32, 4, 1, 0)])
-def test_state_machine_replays_oracle(oracle, harness, fuse_k, w, h, seed, dt, iterations, split_warp):
+@pytest.mark.parametrize("epsilon", [0.01, 0.0])
+def test_state_machine_replays_oracle(oracle, harness, fuse_k, w, h, seed, dt, iterations, split_warp, epsilon):
+    if epsilon == 0.0 and (iterations > 37 or fuse_k not in (1, 4)):
+        pytest.skip("epsilon = 0 (no early exit: the head does not end a segment) is replayed on the short loops")
     I0, I1 = _level_inputs(w, h, seed, dt)
     prm = oracle.tvl1_default_params()
     prm.iterations = iterations
+    prm.epsilon = epsilon
     # oracle: plain host loop
     u1 = np.zeros((h, w), np.float32)
     u2 = np.zeros((h, w), np.float32)
@@ -70,6 +74,10 @@ def test_state_machine_replays_oracle(oracle, harness, fuse_k, w, h, seed, dt, i
     assert steps.value <= int(iters[:5].sum()) + prm.warps
     if split_warp and iterations > 0:  # a warp no longer occupies a step of its own
         assert steps.value <= int(iters[:5].sum())
+    if split_warp == 2 and iterations >= 2 and fuse_k >= 2:
+        # the head takes the first two iterations with it: a warp whose loop ends at its first check costs one step slot
+        # (the launch pair of that step id), not more
+        assert steps.value <= prm.warps + sum(max(0, int(n) - 2 + fuse_k - 1) // fuse_k for n in iters[:5])
 
 
 @pytest.mark.parametrize("shift", [0, 1])
