@@ -62,6 +62,7 @@ struct Tvl1LevelCtx {
     int level;              // level index (0 = full resolution)
     int *iters_out;         // [n_pairs][DFX_LVL_MAX][TVL1_MAX_WARPS] executed inner iterations
     int *checks_out;        // [n_pairs][DFX_LVL_MAX][2] convergence sums evaluated, steps that did work
+    long long *work_out;    // [n_pairs][DFX_LVL_MAX][2] half-row updates per tile column: step kernel, warp-and-head kernel
     // completion signalling
     unsigned int *level_done_count; // device counter of pairs that finished the level
     volatile int *host_done_flag;   // pinned host word: set to done_token when every pair finished

@@ -38,6 +38,9 @@ struct Tvl1State {
     int iters[TVL1_MAX_WARPS]; // statistics: inner iterations executed per warp at this level
     unsigned int ticket;       // arrival counter of the current step's workgroups
     int pad_;
+    // statistics: tile-row updates executed per tile column at this level, in half rows (a primal or a dual update of one
+    // tile row = 1), by the step kernel's tiles and by the warp-and-head kernel's (tvl1_step_work)
+    long long step_work, head_work;
 };
 
 struct Tvl1LoopCfg {
@@ -92,6 +95,20 @@ DFX_HD Tvl1StepPlan tvl1_plan_step(const Tvl1State &s, const Tvl1LoopCfg &c, int
     return p;
 }
 
+// Work of one step of n fused iterations on a 32-row tile with a K-row halo, in half rows (primal / dual update of one
+// tile row): 64 per iteration minus what the trapezoid layout skips (tvl1_tile.h: with d iterations to go the primal
+// update is skipped on rows closer than K - d - 1 to the tile's top / bottom edge, the dual update on rows closer than
+// K - d).  bench.py's useful_frac = owned pixel-iterations / (this x 32 lanes x tiles).
+DFX_HD int tvl1_step_work(int n, int K) {
+    int w = 0;
+    for (int it = 0; it < n; ++it) {
+        const int need = K - (n - 1 - it);
+        const int sp = need - 1 < 0 ? 0 : (need - 1 > 16 ? 16 : need - 1), sd = need < 0 ? 0 : (need > 16 ? 16 : need);
+        w += 64 - 2 * sp - 2 * sd;
+    }
+    return w;
+}
+
 // Start the inner loop of a warp (called when the warp's backward warping has been done at step_id).
 DFX_HD void tvl1_begin_loop(Tvl1State &s, const Tvl1LoopCfg &c, int step_id) {
     s.phase = TVL1_PH_ITER;
@@ -107,7 +124,14 @@ DFX_HD void tvl1_begin_loop(Tvl1State &s, const Tvl1LoopCfg &c, int step_id) {
 }
 
 // Advance after the segment-final step `step_id` (plan p, error = sum(diff) if p.do_check).
+DFX_HD void tvl1_end_segment_core(Tvl1State &s, const Tvl1LoopCfg &c, const Tvl1StepPlan &p, int step_id, double error);
 DFX_HD void tvl1_end_segment(Tvl1State &s, const Tvl1LoopCfg &c, const Tvl1StepPlan &p, int step_id, double error) {
+    // the segment's steps: full ones of fuse_k iterations and the last one (statistics)
+    const int len = p.n_first + p.n_iters - s.seg_n0, last = p.n_iters;
+    s.step_work += (long long)((len - last) / c.fuse_k) * tvl1_step_work(c.fuse_k, c.fuse_k) + tvl1_step_work(last, c.fuse_k);
+    tvl1_end_segment_core(s, c, p, step_id, error);
+}
+DFX_HD void tvl1_end_segment_core(Tvl1State &s, const Tvl1LoopCfg &c, const Tvl1StepPlan &p, int step_id, double error) {
     const int end_n = p.n_first + p.n_iters - 1;
     bool loop_done;
     if (p.do_check) {
@@ -164,8 +188,9 @@ DFX_HD Tvl1StepPlan tvl1_plan_head(const Tvl1State &s, const Tvl1LoopCfg &c) {
 // goes on at iteration n_iters from the set the head wrote.
 DFX_HD void tvl1_end_head(Tvl1State &s, const Tvl1LoopCfg &c, const Tvl1StepPlan &p, int step_id, double error) {
     tvl1_begin_loop(s, c, step_id - 1);
+    s.head_work += tvl1_step_work(p.n_iters, TVL1_HEAD_ITERS);
     if (p.is_last) {
-        tvl1_end_segment(s, c, p, step_id - 1, error);
+        tvl1_end_segment_core(s, c, p, step_id - 1, error);
     } else {
         s.cur = p.src ^ 1;
         s.seg_n0 = p.n_first + p.n_iters;

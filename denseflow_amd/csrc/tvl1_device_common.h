@@ -76,6 +76,8 @@ __device__ __forceinline__ void finish_level(const Tvl1LevelCtx &c, int pair, co
         io[i] = (i < c.loop.warps) ? s.iters[i] : 0;
     c.checks_out[((long long)pair * DFX_LVL_MAX + c.level) * 2 + 0] = s.n_checks;
     c.checks_out[((long long)pair * DFX_LVL_MAX + c.level) * 2 + 1] = step_id + 1; // steps that did work
+    c.work_out[((long long)pair * DFX_LVL_MAX + c.level) * 2 + 0] = s.step_work;
+    c.work_out[((long long)pair * DFX_LVL_MAX + c.level) * 2 + 1] = s.head_work;
     const unsigned old = __hip_atomic_fetch_add(c.level_done_count, 1u, __ATOMIC_RELAXED, AGENT);
     if (old == (unsigned)c.n_pairs - 1u) {
         __hip_atomic_store(c.level_done_count, 0u, __ATOMIC_RELAXED, AGENT);

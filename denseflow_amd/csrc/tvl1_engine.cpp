@@ -63,6 +63,7 @@ class Tvl1Engine final : public AlgoEngine {
     int partials_stride = 0;
     int *d_iters_out = nullptr, *d_checks_out = nullptr;
     int *h_iters = nullptr, *h_checks = nullptr;
+    long long *d_work_out = nullptr, *h_work = nullptr;
     unsigned int *d_level_done = nullptr;
     int *h_done_flag = nullptr, *d_done_flag = nullptr;
     hipEvent_t ev_group[2] = {nullptr, nullptr};
@@ -92,6 +93,8 @@ void Tvl1Engine::destroy() {
     dfx_free_dev(d_partials);
     dfx_free_dev(d_iters_out);
     dfx_free_dev(d_checks_out);
+    dfx_free_dev(d_work_out);
+    dfx_free_host(h_work);
     dfx_free_host(h_iters);
     dfx_free_host(h_checks);
     dfx_free_dev(d_level_done);
@@ -183,6 +186,9 @@ int Tvl1Engine::create() {
     HIPCHK(c, hipMalloc(&d_partials, sizeof(double) * (size_t)partials_stride * B));
     HIPCHK(c, hipMalloc(&d_iters_out, sizeof(int) * B * DFX_LVL_MAX * TVL1_MAX_WARPS));
     HIPCHK(c, hipMalloc(&d_checks_out, sizeof(int) * B * DFX_LVL_MAX * 2));
+    HIPCHK(c, hipMalloc(&d_work_out, sizeof(long long) * B * DFX_LVL_MAX * 2));
+    HIPCHK(c, hipMemset(d_work_out, 0, sizeof(long long) * B * DFX_LVL_MAX * 2));
+    HIPCHK(c, hipHostMalloc(&h_work, sizeof(long long) * B * DFX_LVL_MAX * 2, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc(&h_iters, sizeof(int) * B * DFX_LVL_MAX * TVL1_MAX_WARPS, hipHostMallocDefault));
     HIPCHK(c, hipHostMalloc(&h_checks, sizeof(int) * B * DFX_LVL_MAX * 2, hipHostMallocDefault));
     HIPCHK(c, hipMalloc(&d_level_done, sizeof(unsigned int)));
@@ -268,6 +274,7 @@ Tvl1LevelCtx Tvl1Engine::level_ctx(int s, int n_pairs) const {
     x.level = s;
     x.iters_out = d_iters_out;
     x.checks_out = d_checks_out;
+    x.work_out = d_work_out;
     x.level_done_count = d_level_done;
     x.host_done_flag = d_done_flag;
     x.done_token = 0;
@@ -347,6 +354,8 @@ int Tvl1Engine::run_pairs(int nb, const PairDesc *h_pairs, float *d_out, long lo
                              hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(h_checks, d_checks_out, sizeof(int) * nb * DFX_LVL_MAX * 2, hipMemcpyDeviceToHost,
                              c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_work, d_work_out, sizeof(long long) * nb * DFX_LVL_MAX * 2, hipMemcpyDeviceToHost,
+                             c->stream));
     return DFX_OK;
 }
 
@@ -373,6 +382,11 @@ int Tvl1Engine::account(int nb) {
                 it += h_iters[(b * DFX_LVL_MAX + s) * TVL1_MAX_WARPS + w];
             st.tvl1_total_iters += (uint64_t)it;
             st.tvl1_px_iters += px * (double)it;
+            if (c->prm.impl == 0) { // lane-iterations the tuned kernels executed: half rows x 32 lanes x tiles (tvl1_step_work)
+                Tvl1LevelCtx x = level_ctx(s, 1);
+                st.tvl1_lane_iters += 32.0 * ((double)h_work[(b * DFX_LVL_MAX + s) * 2 + 0] * tvl1_step_blocks(x, 0) +
+                                              (double)h_work[(b * DFX_LVL_MAX + s) * 2 + 1] * tvl1_head_blocks(x));
+            }
             st.algorithmic_bytes += px * (64.0 * (double)it + 44.0 * loop.warps + 28.0);
             st.step_algorithmic_bytes += px * (64.0 * (double)it + 44.0 * loop.warps);
         }

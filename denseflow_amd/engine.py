@@ -93,6 +93,7 @@ class DfxStats(C.Structure):
         ("tvl1_checks", C.c_int),
         ("tvl1_total_iters", C.c_uint64),
         ("tvl1_px_iters", C.c_double),
+        ("tvl1_lane_iters", C.c_double),
     ]
 
     def iters_table(self):

@@ -130,8 +130,8 @@ def test_full_line_schema_and_size():
     out = json.loads(lines[0])
     cfg = out["config"]
     for k in bench.FLAT_KEYS:
-        if k.endswith("traffic_frac") or k == "parity_iters_equal":
-            continue  # PMC-derived: only with a live pass / a matching profiles/pmc_traffic.json entry; iteration tables: GPU only
+        if k.endswith("traffic_frac") or k.endswith("useful_frac") or k == "parity_iters_equal":
+            continue  # PMC- / dfx_stats-derived: only with a live pass on a GPU; iteration tables: GPU only
         assert isinstance(cfg.get(k), float) and math.isfinite(cfg[k]), (k, cfg.get(k))
     assert all(not isinstance(v, (dict, list)) or k in ("pcie_inclusive", "other_workloads") for k, v in cfg.items())
     # whatever the driver's record truncates must be the least important — config's keys are ordered:
@@ -141,11 +141,14 @@ def test_full_line_schema_and_size():
     assert keys[:2] == ["workload", "arithmetic"]
     flat_present = [k for k in bench.FLAT_KEYS if k in cfg]
     assert keys[2:2 + len(flat_present)] == flat_present
-    assert flat_present[:16] == ["parity_pairs", "parity_max_abs", "parity_legs_max_abs",
+    # on a GPU parity_iters_equal and one *_traffic_frac per leg (the bytes that physically moved, beside every frac that
+    # can exceed 1: VERDICT r5 #3) join these, 22 in all in front of the PCIe variants
+    assert flat_present[:14] == ["parity_pairs", "parity_max_abs", "parity_legs_max_abs",
                                  "farn_1080p_pairs_per_s", "farn_1080p_frac", "tvl1_224x64_pairs_per_s", "tvl1_224x64_frac",
-                                 "brox_4k_s2_pairs_per_s", "brox_4k_s2_frac", "tvl1_224_pairs_per_s", "tvl1_224_frac",
-                                 "tvl1_1080p_hard_pairs_per_s", "tvl1_1080p_hard_frac", "tvl1_1080p_hard_iters_per_pair",
-                                 "tvl1_1080p_noexit_pairs_per_s", "tvl1_1080p_noexit_frac"]  # (+ parity_iters_equal on a GPU)
+                                 "brox_4k_s2_pairs_per_s", "brox_4k_s2_frac",
+                                 "tvl1_1080p_hard_pairs_per_s", "tvl1_1080p_hard_frac",
+                                 "tvl1_1080p_noexit_pairs_per_s", "tvl1_1080p_noexit_frac", "tvl1_1080p_noexit_of_ceiling"]
+    assert bench.FLAT_KEYS.index("pcie_jpeg_pairs_per_s") == 21  # the 22nd key: what the driver's record has kept so far
     assert keys.index("pcie_inclusive") > keys.index("pairs_per_step") > keys.index("tvl1_libm_pairs_per_s")
     assert isinstance(out["parity_check"], dict) and {"pairs", "max_abs", "iters_equal"} <= set(out["parity_check"])
     legs = {leg["key"]: leg for leg in cfg["other_workloads"]}
@@ -154,7 +157,47 @@ def test_full_line_schema_and_size():
     for k in ("farn_1080p", "tvl1_224", "tvl1_224x64", "brox_4k_s2"):
         assert "max_abs" in legs[k]["parity_check"], k
     assert "x 64 in one FlowBuffer" in legs["tvl1_224x64"]["workload"] and "19136 pairs/step" in legs["tvl1_224x64"]["workload"]
+    assert "130-frame clip" in legs["brox_4k_s2"]["workload"] and "128 pairs/step" in legs["brox_4k_s2"]["workload"]
     for top in ("roofline", "cpu_baseline"):
         assert isinstance(out[top], dict)
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(out["roofline"])
     assert {"value", "unit", "cores", "kind", "sample"} <= set(out["cpu_baseline"])
+
+
+def _world8(cmd_prefix, env_drop):
+    """The driver's exact SCALE command at N = 8 — `bench.py --gpus 8 --steps 20 --warmup 5`, the headline workload's
+    default arguments — with the stub engine, confined to 16 CPUs like a box of this pool (`taskset`, as many as this
+    container has when it has fewer).  One JSON line, "n_gpus": 8, every rank's 299 pairs counted, well under a minute."""
+    import shutil
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    env["DFX_BENCH_STUB"] = "1"
+    cmd = cmd_prefix + [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    ncpu = len(os.sched_getaffinity(0))
+    if shutil.which("taskset"):
+        cmd = ["taskset", "-c", f"0-{min(16, ncpu) - 1}"] + cmd
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240, cwd=ROOT)
+    wall = time.perf_counter() - t0
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 20 and out["warmup"] == 5 and out["scaling"] == "weak"
+    assert out["config"]["pairs_per_step"] == 8 * 299 and "1920x1080" in out["config"]["workload"]
+    assert abs(out["value"] - 20 * 8 * 299 / (out["ms_per_step"] * 20e-3)) < 1e-6 * out["value"]
+    assert "pcie_inclusive" not in out["config"] and "cpu_baseline" not in out  # N = 1 legs only
+    assert wall < 60.0, wall
+    return out
+
+
+def test_world8_self_launched_as_the_driver_runs_it():
+    """No launcher, no WORLD_SIZE: bench.py starts its own eight ranks on a free port (VERDICT r5 #6)."""
+    _world8([sys.executable], ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE"))
+
+
+def test_world8_under_torch_distributed_run():
+    """The launcher form of the contract: python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py."""
+    _world8([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+             "127.0.0.1", "--master-port", str(_free_port())], ())

@@ -7,8 +7,10 @@
 // FlowBuffer, one JSON line with the rate and the engine's own statistics.  Measurement tooling, not part of the product.
 //
 //   dfx_prof <algo tvl1|farn|brox> <W> <H> <frames.raw> <n_frames> <step> <passes> [max_batch] [variant] [tvl1_math] [block]
+//            [tvl1_epsilon | -1 = default] [clips: the frames are `clips` clips of n_frames / clips frames, one FlowBuffer]
 #include <sys/resource.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +46,9 @@ int main(int argc, char **argv) {
         prm.tvl1_math = std::atoi(argv[10]);
     if (argc > 11)
         prm.blocking_sync = std::atoi(argv[11]);
+    if (argc > 12 && std::atof(argv[12]) >= 0.0)
+        prm.tvl1_epsilon = std::atof(argv[12]);
+    const int clips = argc > 13 ? std::max(1, std::atoi(argv[13])) : 1;
     const size_t fbytes = (size_t)W * H;
     std::vector<uint8_t> frames(fbytes * N);
     FILE *f = std::fopen(argv[4], "rb");
@@ -54,7 +59,11 @@ int main(int argc, char **argv) {
     dfx_handle h = nullptr;
     if (dfx_create(&h, 0, algo, W, H, &prm) != DFX_OK)
         die("dfx_create", h);
-    const int M = N - std::abs(step) > 0 ? N - std::abs(step) : 0;
+    if (N % clips != 0)
+        die("n_frames must be a multiple of clips");
+    const int per_clip = N / clips - std::abs(step) > 0 ? N / clips - std::abs(step) : 0;
+    const int M = per_clip * clips;
+    std::vector<int> seg((size_t)clips, N / clips);
     void *d_frames = nullptr, *d_flows = nullptr;
     if (dfx_device_malloc(h, &d_frames, frames.size()) != DFX_OK ||
         dfx_device_malloc(h, &d_flows, (size_t)M * fbytes * 8) != DFX_OK)
@@ -62,6 +71,8 @@ int main(int argc, char **argv) {
     if (dfx_memcpy_h2d(h, d_frames, frames.data(), frames.size()) != DFX_OK)
         die("upload", h);
     auto pass = [&]() {
+        if (clips > 1 && dfx_next_segments(h, seg.data(), clips) != DFX_OK)
+            die("dfx_next_segments", h);
         if (dfx_calc_batch_device(h, (const uint8_t *)d_frames, (size_t)W, fbytes, N, step, (float *)d_flows,
                                   fbytes * 2) != DFX_OK)
             die("dfx_calc_batch_device", h);
