@@ -142,8 +142,11 @@ __global__ void k_png_bounds(const unsigned *mm, int n, int w, int h, double *bo
     if (i >= n)
         return;
     const double base = 1. / 128.;
-    const double bx = png_bound((double)w, png_unkey(mm[4 * i + 0]), png_unkey(mm[4 * i + 1]));
-    const double by = png_bound((double)h, png_unkey(mm[4 * i + 2]), png_unkey(mm[4 * i + 3]));
+    // a plane without a single comparable value (NaNs only) leaves its keys as armed: minMaxLoc reports 0 / 0 then
+    const bool none_u = mm[4 * i + 0] == 0xffffffffu && mm[4 * i + 1] == 0u;
+    const bool none_v = mm[4 * i + 2] == 0xffffffffu && mm[4 * i + 3] == 0u;
+    const double bx = png_bound((double)w, none_u ? 0.0f : png_unkey(mm[4 * i + 0]), none_u ? 0.0f : png_unkey(mm[4 * i + 1]));
+    const double by = png_bound((double)h, none_v ? 0.0f : png_unkey(mm[4 * i + 2]), none_v ? 0.0f : png_unkey(mm[4 * i + 3]));
     bounds[2 * i] = bx;
     bounds[2 * i + 1] = by;
     PngScale s;

@@ -50,7 +50,9 @@ void orc_flow_to_png_planes(const float *flow_uv, int w, int h, uint8_t *img_x, 
                             uint8_t *img_bgr) {
     const double base = 1. / 128.;
     const size_t n = (size_t)w * h;
-    double mnx = flow_uv[0], mxx = flow_uv[0], mny = flow_uv[1], mxy = flow_uv[1]; /* minMaxLoc: NaNs never win */
+    /* minMaxLoc: the search starts from +-infinity sentinels, so NaNs never win wherever they stand, and a plane without
+     * a single comparable value reports min = max = 0 (upstream minMaxIdx: "if nothing was located, the values are 0") */
+    double mnx = INFINITY, mxx = -INFINITY, mny = INFINITY, mxy = -INFINITY;
     for (size_t p = 0; p < n; ++p) {
         const double u = flow_uv[2 * p], v = flow_uv[2 * p + 1];
         if (u < mnx) mnx = u;
@@ -58,6 +60,8 @@ void orc_flow_to_png_planes(const float *flow_uv, int w, int h, uint8_t *img_x, 
         if (v < mny) mny = v;
         if (v > mxy) mxy = v;
     }
+    if (mnx > mxx) mnx = mxx = 0.0; /* (an all-+inf / all--inf plane keeps its infinity: min <= max there) */
+    if (mny > mxy) mny = mxy = 0.0;
     const double bound_x = png_bound((double)w, mnx, mxx), bound_y = png_bound((double)h, mny, mxy);
     const float ax = (float)(1. / (base * bound_x)), ay = (float)(1. / (base * bound_y));
     const int half = (int)((double)h / 2); /* Point(w - 1, half_h): double -> int by truncation; the box is inclusive */

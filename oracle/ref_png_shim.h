@@ -3,9 +3,15 @@
 // lines can be compiled as they stand (oracle/Makefile, target `ref`): cv::Mat as a plain dense owner / view,
 // minMaxLoc, Mat::convertTo(CV_8UC1, alpha, beta), rectangle(FILLED), mixChannels and Point.  What each stand-in does
 // is OpenCV 4.5.2's documented behaviour for exactly the argument types those lines pass [UPSTREAM-MEM]:
-//   * minMaxLoc(CV_32F): minimum and maximum element as double (NaNs never win a comparison);
+//   * minMaxLoc(CV_32F): minimum and maximum element as double (NaNs never win a comparison; 0 / 0 for a plane of NaNs);
 //   * convertTo(CV_8U, alpha, beta) from CV_32F: saturate_cast<uchar>(src * (float)alpha + (float)beta), the product
-//     and the sum rounded separately in float, saturate_cast = cvRound (round half to even) clamped to [0, 255];
+//     and the sum rounded separately in float, saturate_cast = cvRound (round half to even) clamped to [0, 255].
+//     AN ASSUMPTION, NOT A PIN: this is the scalar tail of cv::cvt_32f8u.  The vector body of OpenCV 4.x's
+//     cvt32f8u is written with v_fma / v_muladd, which the AVX2 / FMA3 dispatch executes as ONE fused operation: a real
+//     cv::imencode input may then differ from this reading by 1 LSB at pixels where src * alpha + 128 lands within half a
+//     float ulp of a .5 tie (rare; never on an all-zero flow).  The device (quantize_kernels.hip: png_cast) and
+//     oracle/quant_oracle.c follow this unfused reading; tests/test_opencv_pin.py's kit is where a real OpenCV build
+//     settles it, and a fused variant is a one-line change in all three places;
 //   * rectangle(img, Point a, Point b, Scalar v, FILLED): every pixel of the inclusive box [a, b] clipped to the image
 //     set to saturate_cast<uchar>(v); Point(double, double) converts by cvRound? NO — Point_<int>(w - 1, half_h) is the
 //     int constructor: the doubles the reference passes are converted by the C++ implicit conversion = truncation;
@@ -61,7 +67,9 @@ struct Mat {
 };
 
 static inline void minMaxLoc(const Mat &m, double *mn, double *mx) {
-    double lo = m.at<float>(0, 0), hi = lo;
+    // upstream minMaxIdx searches from +-infinity sentinels (a NaN never wins, wherever it stands) and reports 0 / 0
+    // when it located nothing — a plane of NaNs only [UPSTREAM-MEM]
+    double lo = INFINITY, hi = -INFINITY;
     for (int i = 0; i < m.rows; ++i)
         for (int j = 0; j < m.cols; ++j) {
             const double v = m.at<float>(i, j);
@@ -70,6 +78,8 @@ static inline void minMaxLoc(const Mat &m, double *mn, double *mx) {
             if (v > hi)
                 hi = v;
         }
+    if (lo > hi)
+        lo = hi = 0.0;
     *mn = lo;
     *mx = hi;
 }

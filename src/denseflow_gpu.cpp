@@ -1027,7 +1027,8 @@ void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_di
     // processes on ONE device (DF_DEVICES=0,0) overlap their launch gaps and host phases where two handles of one process
     // share a HIP runtime and do not (round 2: 403 -> 430 pairs/s for TVL1 at 1080p); it is also the rehearsal of an
     // N-rank launch on a one-GPU box.  The parent must not have touched HIP before the fork (tools/denseflow.cpp takes the
-    // device list from DF_DEVICES then), builds nothing itself and only adds up the children's counts.
+    // device list from DF_DEVICES then, or counts the devices in a child of their own), builds nothing itself and only adds
+    // up the children's counts.
     static const bool use_processes = std::getenv("DF_PROCESSES") != nullptr;
     unsigned long N = 0, F = 0;
     if (use_processes && G > 1) {
@@ -1044,6 +1045,8 @@ void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_di
                 throw std::runtime_error("fork() failed");
             if (pid == 0) { // child: its own pipeline, its own HIP runtime
                 close(pp[0]);
+                for (size_t k = 0; k < g; ++k) // the read ends of the children started before this one
+                    close(fds[k]);
                 int rc = 0;
                 try {
                     if (step == 0)
@@ -1055,6 +1058,8 @@ void calcDenseFlowVideoMultiGPU(vector<path> video_paths, vector<path> output_di
                         rc = 1;
                 } catch (const std::exception &ex) {
                     cout << ex.what() << endl;
+                    rc = 1;
+                } catch (...) { // whatever it is, the child must reach _exit and never run the parent's code below
                     rc = 1;
                 }
                 std::cout.flush();

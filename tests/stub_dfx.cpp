@@ -10,6 +10,7 @@
 // orc_brox_calc with the reference's default parameters) instead of the made-up one — BASELINE.json's configs[0] / SURVEY.md
 // section 8d "Config 1": the CLI on a CPU, plumbing only (file names, bounding, encoding, "oracle == backend").  Still test
 // infrastructure: the oracle is reachable from tests/ only.
+#include <unistd.h>
 #include <cstdio>
 #include <dlfcn.h>
 #include <cstdlib>
@@ -119,6 +120,8 @@ int prepare(dfx_context *c, const uint8_t *const *frames, size_t pitch, int n_fr
 extern "C" {
 
 int dfx_device_count(void) {
+    if (std::getenv("STUB_TRACE_DEVICE_COUNT"))
+        std::fprintf(stderr, "stub: dfx_device_count in pid %d\n", (int)getpid());
     const char *e = std::getenv("STUB_DEVICES");
     return e ? std::atoi(e) : 1;
 }

@@ -213,11 +213,19 @@ def test_pipelines_as_processes_write_the_same_files(stub, tmp_path, what):
         (tmp_path / "list.txt").write_text("\n".join(lines) + "\n")
         src, n_frames, n_flows = tmp_path / "list.txt", sum(6 + i for i in range(5)), sum(5 + i for i in range(5))
     outs = {}
-    for tag, env in (("one", {}), ("threads", {"DF_DEVICES": "0,0,0"}), ("procs", {"DF_DEVICES": "0,0,0", "DF_PROCESSES": "1"})):
-        r = _run(stub, [src, "-o=" + str(tmp_path / tag), "-a=farn", "-s=1", "-b=20"], env)
+    # "procs -g": -g=3 with DF_PROCESSES and NO device list — the parent counts the devices in a child of their own and
+    # stays free of the runtime it is about to fork away from (the stub offers STUB_DEVICES of them)
+    for tag, env in (("one", {}), ("threads", {"DF_DEVICES": "0,0,0"}), ("procs", {"DF_DEVICES": "0,0,0", "DF_PROCESSES": "1"}),
+                     ("procs -g", {"DF_PROCESSES": "1", "STUB_DEVICES": "3", "STUB_TRACE_DEVICE_COUNT": "1"})):
+        extra = ["-g=3"] if tag == "procs -g" else []
+        r = _run(stub, [src, "-o=" + str(tmp_path / tag), "-a=farn", "-s=1", "-b=20"] + extra, env)
+        if tag == "procs -g":  # the library was asked for its devices — never by the CLI's own process (children: the
+            pids = [ln.split()[-1] for ln in r.stderr.splitlines() if ln.startswith("stub: dfx_device_count in pid")]  # counter + pipelines)
+            main = [ln.split()[-1] for ln in r.stderr.splitlines() if ln.startswith("stub: main pid")]
+            assert pids and len(main) == 1 and main[0] not in pids, r.stderr
         outs[tag] = {k: v for k, v in _files(tmp_path / tag).items() if ".done" not in k}
         assert f"{n_flows} farn flows) processed" in r.stdout, r.stdout
-    assert outs["one"] and outs["threads"] == outs["one"] and outs["procs"] == outs["one"]
+    assert outs["one"] and outs["threads"] == outs["one"] and outs["procs"] == outs["one"] and outs["procs -g"] == outs["one"]
     r = subprocess.run([stub, str(src), "-o=" + str(tmp_path / "bad"), "-a=farn", "-s=1"], capture_output=True, text=True,
                        env={**os.environ, "DF_DEVICES": "0,0", "DF_PROCESSES": "1", "STUB_FAIL_SUBMIT": "1"})
     assert r.returncode != 0 and "a pipeline process failed" in r.stdout, r.stdout + r.stderr

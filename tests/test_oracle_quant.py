@@ -122,3 +122,27 @@ def test_png_scheme_oracle_equals_compiled_reference_on_fresh_inputs(oracle):
         flow = flow_with_extrema(w, h, float(rng.choice([0.0, 0.3, 7.9, 15.5, 31.7, 300.0])),
                                  float(rng.choice([0.0, 1.0, 3.9, 23.6, 64.0])), 200 + k, bool(k & 1))
         assert np.array_equal(oracle.flow_to_png_planes(flow)[3], oracle.ref_flow_to_png_image(flow)), (w, h, k)
+
+
+def _nan_flows(w=33, h=21):
+    """minMaxLoc on flows with NaNs: at the very first element (a search seeded with it would be stuck), a whole plane of
+    them (nothing located: minMaxLoc reports 0 / 0, the bound rule gives 4 — ADVICE r5), both planes, and a clean one."""
+    rng = np.random.default_rng(5)
+    base = (rng.standard_normal((h, w, 2)) * np.array([9.0, 3.0])).astype(np.float32)
+    first = base.copy(); first[0, 0, :] = np.nan
+    u_nan = base.copy(); u_nan[..., 0] = np.nan
+    both = np.full_like(base, np.nan)
+    sprinkled = base.copy(); sprinkled[rng.random((h, w)) < 0.3] = np.nan
+    return {"clean": base, "NaN first": first, "u all NaN": u_nan, "all NaN": both, "30 % NaN": sprinkled}
+
+
+def test_png_scheme_nan_rules(oracle):
+    flows = _nan_flows()
+    want = oracle.flow_to_png_planes(flows["clean"])[2]
+    assert oracle.flow_to_png_planes(flows["NaN first"])[2] == want  # one NaN pixel does not move the extrema of 693
+    x, y, b, _ = oracle.flow_to_png_planes(flows["u all NaN"])
+    assert b == (4.0, want[1]) and not x.any()  # NaN -> cvRound = INT_MIN -> saturates to 0
+    assert oracle.flow_to_png_planes(flows["all NaN"])[2] == (4.0, 4.0)
+    if oracle.ref_png_available():  # the reference's own lines over the stand-in minMaxLoc / convertTo
+        for name, f in flows.items():
+            assert np.array_equal(oracle.ref_flow_to_png_image(f), oracle.flow_to_png_planes(f)[3]), name

@@ -61,6 +61,19 @@ def test_matches_oracle_on_flows_built_for_the_bound_rule(dfx, oracle, w, h):
         assert np.array_equal(x[i], ox) and np.array_equal(y[i], oy), (w, h, i)
 
 
+def test_nan_rules(dfx, oracle):
+    """NaNs never win minMaxLoc wherever they stand; a plane of NaNs only locates nothing: 0 / 0, bound 4 (the
+    device used to report a NaN bound there)."""
+    from tests.test_oracle_quant import _nan_flows
+
+    flows = _nan_flows()
+    x, y, b = _png_on_device(dfx, np.stack(list(flows.values())))
+    for i, (name, f) in enumerate(flows.items()):
+        ox, oy, ob, _ = oracle.flow_to_png_planes(f)
+        assert tuple(b[i]) == ob and np.isfinite(b[i]).all(), (name, tuple(b[i]), ob)
+        assert np.array_equal(x[i], ox) and np.array_equal(y[i], oy), name
+
+
 def test_padded_rows_and_strided_planes(dfx, oracle):
     w, h = 50, 21
     flows = np.stack([flow_with_extrema(w, h, 6.0 + i, 2.5, 70 + i) for i in range(2)])

@@ -4,6 +4,8 @@
 // `denseflow -h` listing in /root/reference/README.md:109-143 (cv::CommandLineParser semantics: `-k=v`,
 // bare `-k` is a boolean presence, other tokens are positional).  One key is added:
 // `-g, --gpus` (number of GPUs to shard a list.txt over, default 1).
+#include <sys/wait.h>
+#include <unistd.h>
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -134,6 +136,21 @@ class CommandLine {
 
 } // namespace
 
+// dfx_device_count() in a forked child (exit status = count, capped at 255): the caller's process stays free of HIP.
+static int device_count_in_a_child() {
+    std::cout.flush();
+    std::cerr.flush();
+    const pid_t pid = fork();
+    if (pid < 0)
+        return 0;
+    if (pid == 0)
+        _exit(std::min(std::max(dfx_device_count(), 0), 255));
+    int status = 0;
+    if (waitpid(pid, &status, 0) != pid || !WIFEXITED(status))
+        return 0;
+    return WEXITSTATUS(status);
+}
+
 int main(int argc, char **argv) {
     try {
         CommandLine cmd(argc, argv);
@@ -194,10 +211,15 @@ int main(int argc, char **argv) {
         }
         if (!video_paths.empty()) {
             vector<int> devices;
-            // DF_PROCESSES=1 forks one process per pipeline: this process must not start the HIP runtime then, so the device
-            // list is taken from DF_DEVICES as it stands (each child fails with the library's message on a bad index)
-            const bool forked = std::getenv("DF_PROCESSES") && std::getenv("DF_DEVICES");
-            const int avail = forked ? (1 << 16) : std::max(dfx_device_count(), 1);
+            // DF_PROCESSES=1 forks one process per pipeline: THIS process must not start the HIP runtime then (a runtime
+            // inherited across fork() is undefined: the children hang or fail in dfx_create).  With DF_DEVICES the list is
+            // taken as it stands (each child fails with the library's message on a bad index); without it the devices are
+            // counted by a short-lived child of their own.
+            const bool by_processes = std::getenv("DF_PROCESSES") != nullptr;
+            if (std::getenv("STUB_TRACE_DEVICE_COUNT")) // tests/test_host_pipeline_stub.py: which process asks the library
+                std::cerr << "stub: main pid " << (int)getpid() << std::endl;
+            const bool forked = by_processes && std::getenv("DF_DEVICES");
+            const int avail = forked ? (1 << 16) : std::max(by_processes ? device_count_in_a_child() : dfx_device_count(), 1);
             for (int g = 0; g < std::max(1, std::min(gpus, avail)); ++g)
                 devices.push_back(g);
             if (const char *dl = std::getenv("DF_DEVICES")) { // explicit device list, e.g. "2,3" or (testing) "0,0"
