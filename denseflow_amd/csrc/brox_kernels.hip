@@ -328,7 +328,17 @@ __global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, in
 //     against IEEE division over the Brox range of denominators, tests/test_device_math_gpu.py) on both pixels at once.
 typedef float f2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 
-template <int S>
+// SYNC (round 6): how a half sweep waits for the one before it.
+//   0  __syncthreads(): every half sweep of the tile is one phase of all sixteen waves — they read LDS together, run their
+//      dependent update chains together and meet at the barrier together: ~1400 cycles per half sweep for ~620 VALU and
+//      ~640 LDS cycles that never overlap (profiles/round3/brox/);
+//   1  band by band: a wave owns 4 tile rows, and half sweep t of a band depends only on half sweep t - 1 of the bands
+//      above and below it (colour c reads colour 1 - c at the four neighbours and writes colour c: a read-after-write and a
+//      write-after-read on the neighbour bands' edge rows, both settled once THOSE bands have finished t - 1).  Each wave
+//      publishes its progress in LDS (release) and waits for its two neighbours' (acquire): no workgroup barrier inside
+//      the sweeps, the waves drift apart and one band's LDS phase overlaps another's arithmetic.  Same updates, same
+//      order per pixel: bit-identical.
+template <int S, int SYNC>
 __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set, int d_src, int n_sweeps, int tiles_x) {
     constexpr int TW = 64, TH = 64, HALO = 2 * S;
     // w = u + du and v + dv of the tile, split by column parity: W*[x & 1][y][x >> 1].  A lane owns columns 2 * pcol and
@@ -339,6 +349,7 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
     // W*[1 - k][y][p -/+ 1].
     __shared__ float WU[2][TH][TW / 2];
     __shared__ float WV[2][TH][TW / 2];
+    __shared__ int progress[TH / 4]; // SYNC = 1: half sweeps completed per band
 #define WU_AT(ly, lx) WU[(lx)&1][ly][(lx) >> 1]
 #define WV_AT(ly, lx) WV[(lx)&1][ly][(lx) >> 1]
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
@@ -427,6 +438,8 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
     const f2 nu[2] = BROX_PAIR(r_nu), nv[2] = BROX_PAIR(r_nv), uu[2] = BROX_PAIR(r_u), vv[2] = BROX_PAIR(r_v);
     f2 du[2] = BROX_PAIR(r_du), dv[2] = BROX_PAIR(r_dv);
 #undef BROX_PAIR
+    if (SYNC == 1 && threadIdx.x < TH / 4)
+        progress[threadIdx.x] = 0;
     __syncthreads();
 
     // neighbour coordinates, clamped at the tile edge exactly like max(lx - 1, 0) / min(lx + 1, TW - 1) of the definition's
@@ -438,13 +451,30 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
 #if BROX_SOR_DEBUG == 1 // measurement build only (scripts/build_variant.sh): load and store phases without the sweeps (WRONG flows)
     n_sweeps = 0;
 #endif
+    const int band = ly0 / ROWS_PER_WAVE, lane = threadIdx.x & 63;
     for (int sw = 0; sw < n_sweeps; ++sw) {
         // a wavefront whose rows can no longer influence the owned region skips its updates: after sweep s of n the
         // result is needed on the owned rows +- (2 (n - 1 - s) + 1)
         const int m = 2 * (n_sweeps - 1 - sw) + 1;
         const bool live = band0 + ROWS_PER_WAVE - 1 >= HALO - m && band0 < TH - HALO + m;
+        if (SYNC == 1 && !live) { // dead from here on (m only shrinks): nobody must wait for this band again
+            if (lane == 0)
+                __hip_atomic_store(&progress[band], 1 << 20, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            if (SYNC == 1) { // the bands above and below have finished half sweep t - 1
+                const int t = 2 * sw + q;
+                if (band > 0)
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&progress[band - 1], __ATOMIC_ACQUIRE,
+                                                                            __HIP_MEMORY_SCOPE_WORKGROUP)) < t)
+                        __builtin_amdgcn_s_sleep(1);
+                if (band < TH / ROWS_PER_WAVE - 1)
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&progress[band + 1], __ATOMIC_ACQUIRE,
+                                                                            __HIP_MEMORY_SCOPE_WORKGROUP)) < t)
+                        __builtin_amdgcn_s_sleep(1);
+            }
             if (live) {
                 // element 0 = (ly0, lx0 + q), element 1 = (ly0 + 1, lx0 + 1 - q)
                 const int ax = lx0 + q, bx = lx0 + 1 - q;
@@ -468,7 +498,13 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
                 WV_AT(ly0, ax) = wv.x;
                 WV_AT(ly0 + 1, bx) = wv.y;
             }
-            __syncthreads();
+            if (SYNC == 1) { // publish: the release orders the wave's LDS writes (one wait counter per wave) in front of it
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0)
+                    __hip_atomic_store(&progress[band], 2 * sw + q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __syncthreads();
+            }
         }
     }
     // ---- store the owned region into the other du / dv set
@@ -586,7 +622,10 @@ void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int
     constexpr int TW = 64, TH = 64, S = BROX_SWEEPS;
     const int tiles_x = (c.w + (TW - 4 * S) - 1) / (TW - 4 * S), tiles_y = (c.h + (TH - 4 * S) - 1) / (TH - 4 * S);
     const dim3 grid(tiles_x * tiles_y, 1, c.n_pairs), block(TW * TH / 4);
-    hipLaunchKernelGGL((k_brox_sor_pk<S>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
+    if (c.sor_barrier)
+        hipLaunchKernelGGL((k_brox_sor_pk<S, 0>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
+    else
+        hipLaunchKernelGGL((k_brox_sor_pk<S, 1>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
 }
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set) {
     hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set);

@@ -81,8 +81,11 @@ def test_large_pyramid_1080p(dfx, oracle):
 def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
     """The fused SOR kernel (LDS tile split by column parity, recomputed halo, five sweeps per launch, 8-byte loads, the
     two pixels of a half sweep as packed float2 math, exact Newton reciprocals) must not change a bit relative to the
-    simple one-launch-per-half-sweep form, for even and odd solver-iteration counts."""
-    knobs = {}
+    simple one-launch-per-half-sweep form, for even and odd solver-iteration counts — in both of its synchronisation
+    forms: band-wise progress counters (round 6, the default: a wave waits for the two bands next to it, not for the
+    workgroup) and a workgroup barrier per half sweep (DFX_VAR_BROX_SOR_BARRIER, rounds 2-5)."""
+    from denseflow_amd import engine as E
+
     # large enough that workgroups of one launch are NOT all co-resident: an in-place update of du/dv would
     # race with neighbours reading their halo (this caught exactly that bug; the kernels ping-pong two sets).
     # odd width and height: the right-most 8-byte pair and the last patch row straddle the image border
@@ -92,9 +95,12 @@ def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
         for solver in (10, 3, 7):
             with dfx.FlowEngine(w, h, "brox", impl=1, brox_solver_iterations=solver) as eng:
                 simple = eng.calc(f0, f1)
-            with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver, **knobs) as eng:
-                fused = eng.calc(f0, f1)
-            assert np.array_equal(simple.view(np.uint32), fused.view(np.uint32)), (w, h, solver)
+            for variant in (0, E.VAR_BROX_SOR_BARRIER):
+                with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver, variant=variant) as eng:
+                    fused = eng.calc(f0, f1)
+                    again = eng.calc(f0, f1)  # (a race between bands would not repeat itself)
+                assert np.array_equal(simple.view(np.uint32), fused.view(np.uint32)), (w, h, solver, variant)
+                assert np.array_equal(fused.view(np.uint32), again.view(np.uint32)), (w, h, solver, variant)
 
 
 @pytest.mark.parametrize("w,h,seed,t0,t1", [(224, 224, 1, 0, 8), (80, 56, 21, 0, 2), (40, 33, 4, 0, 3)])
