@@ -164,7 +164,7 @@ BroxLevelCtx BroxEngine::level_ctx(int l, int nb) const {
     x.alpha = c->prm.brox_alpha;
     x.gamma = c->prm.brox_gamma;
     x.omega = 1.99f;
-    x.sor_barrier = (c->prm.variant & DFX_VAR_BROX_SOR_BARRIER) ? 1 : 0;
+    x.sor_progress = (c->prm.variant & DFX_VAR_BROX_SOR_PROGRESS) ? 1 : 0;
     return x;
 }
 

@@ -28,7 +28,7 @@ struct BroxLevelCtx {
     const PairDesc *pairs;
     int n_pairs;
     float alpha, gamma, omega;
-    int sor_barrier;          // fused SOR: a workgroup barrier per half sweep (DFX_VAR_BROX_SOR_BARRIER) instead of band-wise progress
+    int sor_progress;         // fused SOR: band-wise progress counters (DFX_VAR_BROX_SOR_PROGRESS) instead of a barrier per half sweep
 };
 
 void brox_launch_u8_to_f32(hipStream_t s, const unsigned char *src, long long src_frame_stride, long long src_pitch,

@@ -329,15 +329,19 @@ __global__ __launch_bounds__(256) void k_brox_sor(BroxLevelCtx c, int uv_set, in
 typedef float f2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 
 // SYNC (round 6): how a half sweep waits for the one before it.
-//   0  __syncthreads(): every half sweep of the tile is one phase of all sixteen waves — they read LDS together, run their
-//      dependent update chains together and meet at the barrier together: ~1400 cycles per half sweep for ~620 VALU and
-//      ~640 LDS cycles that never overlap (profiles/round3/brox/);
-//   1  band by band: a wave owns 4 tile rows, and half sweep t of a band depends only on half sweep t - 1 of the bands
-//      above and below it (colour c reads colour 1 - c at the four neighbours and writes colour c: a read-after-write and a
-//      write-after-read on the neighbour bands' edge rows, both settled once THOSE bands have finished t - 1).  Each wave
-//      publishes its progress in LDS (release) and waits for its two neighbours' (acquire): no workgroup barrier inside
-//      the sweeps, the waves drift apart and one band's LDS phase overlaps another's arithmetic.  Same updates, same
-//      order per pixel: bit-identical.
+//   0  __syncthreads() (the default): every half sweep of the tile is one phase of all sixteen waves — they read LDS
+//      together, run their dependent update chains together and meet at the barrier together: ~1400 cycles per half sweep
+//      for ~620 VALU and ~640 LDS cycles that never overlap (profiles/round3/brox/);
+//   1  band by band (DFX_VAR_BROX_SOR_PROGRESS): a wave owns 4 tile rows, and half sweep t of a band depends only on half
+//      sweep t - 1 of the bands above and below it (colour c reads colour 1 - c at the four neighbours and writes colour c:
+//      a read-after-write and a write-after-read on the neighbour bands' edge rows, both settled once THOSE bands have
+//      finished t - 1).  Each wave publishes its progress in LDS (release) and waits for its two neighbours' (acquire): no
+//      workgroup barrier inside the sweeps.  Same updates, same order per pixel: bit-identical — and 7 % SLOWER (232 vs
+//      249 pairs/s at 1080p, 59.2 vs 63.5 at 4K -s=2; profiles/round6/brox/): because every band needs BOTH neighbours'
+//      previous half sweep, no band can run ahead of the one next to it at all — the dependency graph has the barrier's
+//      shape, only its implementation got more expensive (two polled LDS words and a release fence per wave and half
+//      sweep).  What would decouple the phases is a second, independent tile on the same CU, and the register file has no
+//      room for one (a 64 x 64 tile's 14 values per pixel are 224 KB of its 512 KB): DESIGN.md section 4.
 template <int S, int SYNC>
 __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set, int d_src, int n_sweeps, int tiles_x) {
     constexpr int TW = 64, TH = 64, HALO = 2 * S;
@@ -622,10 +626,10 @@ void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int
     constexpr int TW = 64, TH = 64, S = BROX_SWEEPS;
     const int tiles_x = (c.w + (TW - 4 * S) - 1) / (TW - 4 * S), tiles_y = (c.h + (TH - 4 * S) - 1) / (TH - 4 * S);
     const dim3 grid(tiles_x * tiles_y, 1, c.n_pairs), block(TW * TH / 4);
-    if (c.sor_barrier)
-        hipLaunchKernelGGL((k_brox_sor_pk<S, 0>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
-    else
+    if (c.sor_progress)
         hipLaunchKernelGGL((k_brox_sor_pk<S, 1>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
+    else
+        hipLaunchKernelGGL((k_brox_sor_pk<S, 0>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
 }
 void brox_launch_add_increment(hipStream_t s, const BroxLevelCtx &c, int uv_set, int d_set) {
     hipLaunchKernelGGL(k_brox_add_increment, bgrid(c.w, c.h, c.n_pairs), dim3(256), 0, s, c, uv_set, d_set);

@@ -82,8 +82,8 @@ def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
     """The fused SOR kernel (LDS tile split by column parity, recomputed halo, five sweeps per launch, 8-byte loads, the
     two pixels of a half sweep as packed float2 math, exact Newton reciprocals) must not change a bit relative to the
     simple one-launch-per-half-sweep form, for even and odd solver-iteration counts — in both of its synchronisation
-    forms: band-wise progress counters (round 6, the default: a wave waits for the two bands next to it, not for the
-    workgroup) and a workgroup barrier per half sweep (DFX_VAR_BROX_SOR_BARRIER, rounds 2-5)."""
+    forms: a workgroup barrier per half sweep (the default) and band-wise progress counters (round 6,
+    DFX_VAR_BROX_SOR_PROGRESS: a wave waits for the two bands next to it, not for the workgroup; measured slower, kept)."""
     from denseflow_amd import engine as E
 
     # large enough that workgroups of one launch are NOT all co-resident: an in-place update of du/dv would
@@ -95,7 +95,7 @@ def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
         for solver in (10, 3, 7):
             with dfx.FlowEngine(w, h, "brox", impl=1, brox_solver_iterations=solver) as eng:
                 simple = eng.calc(f0, f1)
-            for variant in (0, E.VAR_BROX_SOR_BARRIER):
+            for variant in (0, E.VAR_BROX_SOR_PROGRESS):
                 with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver, variant=variant) as eng:
                     fused = eng.calc(f0, f1)
                     again = eng.calc(f0, f1)  # (a race between bands would not repeat itself)
