@@ -145,3 +145,6 @@ extern "C" int ctrl_xcd_map_check(int nt) {
     }
     return 0;
 }
+
+// tvl1_step_work (bench.py's useful_frac): exported for the row-by-row recount of tests/test_ctrl_logic.py
+extern "C" int ctrl_step_work(int n, int K) { return tvl1_step_work(n, K); }

@@ -111,3 +111,21 @@ def test_xcd_aware_tile_mapping_is_a_bijection(harness):
     harness.ctrl_xcd_map_check.restype = C.c_int
     for nt in list(range(1, 300)) + [1020, 1100, 1248, 1575, 2040, 30 * 270, 65537]:
         assert harness.ctrl_xcd_map_check(nt) == 0, nt
+
+
+def test_step_work_counts_what_the_trapezoid_layout_executes(harness):
+    """tvl1_step_work(n, K) — the half rows a step of n iterations updates on a 32-row tile with a K-row halo, which the
+    state machine adds up per level for dfx_stats.tvl1_lane_iters / bench.py's useful_frac — against a row-by-row count of
+    tvl1_tile.h's skip rule (with d iterations to go, primal updates are skipped on rows closer than K - d - 1 to the
+    tile's top / bottom edge, dual updates on rows closer than K - d)."""
+    harness.ctrl_step_work.argtypes = [C.c_int, C.c_int]
+    harness.ctrl_step_work.restype = C.c_int
+    for K in range(1, 13):
+        for n in range(1, K + 1):
+            work = 0
+            for it in range(n):
+                need = K - (n - 1 - it)
+                for a in range(16):  # float2 a rows from the edge = two tile rows
+                    work += 2 * (0 if a < need - 1 else 1) + 2 * (0 if a < need else 1)
+            assert harness.ctrl_step_work(n, K) == work, (n, K)
+    assert harness.ctrl_step_work(4, 4) == 224  # of 256: the 12.5 % a full step skips
