@@ -5,12 +5,10 @@
 // Why: on converging content a pair spends 25 warps per pyramid, and 20 of them (warps 1-4 of every level) consist of the
 // warp and ONE two-iteration step — the first convergence check is due at iteration 1 and passes.  As two launches that
 // costs, per pixel, the warp's 3 + 3 plane reads and 3 plane writes plus the step's 9 reads (x 1.5 with its 4-pixel halo)
-// and 6 writes; both are bound by HBM latency / bandwidth, not arithmetic.  Here one workgroup
-//   1. copies the (64 + 24) x (32 + 14) neighbourhood of I1 of its 64 x 32 tile into LDS (aligned 16-byte row loads,
-//      clamp-to-edge applied while copying — the tile of k_tvl1_warp_lds grown to the step kernel's tile) and forms the
-//      centred gradient I1x, I1y of the (64 + 16) x (32 + 12) window region there (k_centered_gradient's expression on
-//      the same operands: the same bits as the I1x / I1y pyramids hold, which only the far-flow fallback still reads),
-//   2. warps the tile's 8 rows per thread from it — I1wx, I1wy, rho_c land in the registers the iterations read them from,
+// and 6 writes, in kernels that run at 4.4-4.9 TB/s of their own bytes.  Here one workgroup
+//   1. copies the (64 + 16) x (32 + 12) neighbourhood of I1, I1x, I1y of its 64 x 32 tile into LDS (aligned 16-byte row
+//      loads, clamp-to-edge applied while copying — the tile of k_tvl1_warp_lds grown to the step kernel's tile),
+//   2. warps the tile's 8 rows per thread from it, two pixels at a time as packed float2 math — I1wx, I1wy, rho_c land in the registers the iterations read them from,
 //      the same pixel taking the same bits whichever tile (owner or halo) computes it: warp_finish on the same taps,
 //   3. re-uses the LDS for the iteration's neighbour planes and runs the head of the loop (TVL1_HEAD_ITERS = 2 iterations,
 //      2-pixel halo: a tile owns 60 x 28 of its 64 x 32 pixels) with the packed tile function of the step kernel
@@ -18,7 +16,11 @@
 //   4. stores u / p of the owned region into the other ping-pong set AND I1wx / I1wy / rho_c (a loop that goes on reads
 //      them in the step kernel), publishes its share of the convergence sum; the last workgroup of the pair advances the
 //      state machine (tvl1_ctrl.h: tvl1_plan_head / tvl1_end_head).
-// Per owned pixel: 10.9 words read (7 planes x 1.22 + the I1 tile's 2.4) + 9 written, against 31.3 for the two launches.
+// Per owned pixel: 14.8 words read (7 planes x 1.22 + the image tiles' 6.3; 10 for a level's first warp, whose dual planes
+// are zero by definition and are not read) + 9 written, against 31.3 for the two launches.  The kernel issues VALU
+// instructions 3/4 of the time (SQ counters, profiles/round6/): forming I1x / I1y in LDS from a wider I1 tile instead of
+// reading them (16 KB instead of 42 KB per tile) was measured SLOWER for that reason, as were hand-scheduled tap loads
+// (LABNOTES.md section 11).
 // Compiled with -ffp-contract=off (see tvl1_math.h).
 #include <hip/hip_runtime.h>
 
