@@ -40,6 +40,7 @@ class BroxEngine final : public AlgoEngine {
     float *d_frames = nullptr;
     int *d_frame_slots = nullptr, *h_slots_pinned = nullptr;
     int B = 0;
+    int n_cu = 0; // compute units of the device: the streaming SOR runs one persistent workgroup on each
     float *d_planes = nullptr;
     long long plane_stride = 0, slot_stride = 0;
     PairDesc *d_pairs = nullptr, *h_pairs_pinned = nullptr;
@@ -68,6 +69,11 @@ int BroxEngine::create() {
     if (!(p.brox_scale_factor > 0.f && p.brox_scale_factor < 1.f) || !(p.brox_alpha > 0.f) ||
         p.brox_inner_iterations < 0 || p.brox_outer_iterations < 1 || p.brox_solver_iterations < 0)
         return dfx_fail(c, DFX_ERR_INVALID, "invalid Brox parameters");
+    {
+        int dev = 0;
+        HIPCHK(c, hipGetDevice(&dev));
+        HIPCHK(c, hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
     // pyramid sizes: scale accumulated in float, ceilf, until a side is <= 15 px or outer_iterations levels
     {
         float scale = 1.0f;
@@ -165,6 +171,7 @@ BroxLevelCtx BroxEngine::level_ctx(int l, int nb) const {
     x.gamma = c->prm.brox_gamma;
     x.omega = 1.99f;
     x.sor_progress = (c->prm.variant & DFX_VAR_BROX_SOR_PROGRESS) ? 1 : 0;
+    x.sor_stream = (c->prm.variant & (DFX_VAR_BROX_SOR_PROGRESS | DFX_VAR_BROX_SOR_PER_TILE)) ? 0 : n_cu;
     return x;
 }
 

@@ -28,6 +28,8 @@ struct BroxLevelCtx {
     const PairDesc *pairs;
     int n_pairs;
     float alpha, gamma, omega;
+    int sor_stream;           // fused SOR: persistent workgroups (this many: the device's CUs) that prefetch the next tile's
+                              // coefficient planes by LDS-DMA while they sweep (0: one workgroup per tile, DFX_VAR_BROX_SOR_PER_TILE)
     int sor_progress;         // fused SOR: band-wise progress counters (DFX_VAR_BROX_SOR_PROGRESS) instead of a barrier per half sweep
 };
 

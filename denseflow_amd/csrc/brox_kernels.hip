@@ -8,6 +8,7 @@
 // the oracle's operation order and the file is compiled with -ffp-contract=off, so results are bit-identical
 // to the oracle.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdlib>
 
 #include "brox_kernels.h"
@@ -534,6 +535,212 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
 #undef WU_AT
 #undef WV_AT
 
+// ------------------------------------------------------------------------------------------------
+// The streaming form of the fused SOR (round 6): ONE persistent 1024-thread workgroup per CU walks over tiles, and while it
+// sweeps tile i the seven coefficient planes of tile i + 1 (GX, GY, IDU, IDV, NDUDV, NU, NV: 64 x 64 floats each, 112 KB of
+// the CU's 160 KB of LDS) arrive by LDS-DMA (global_load_lds: no registers, no VALU).  Why: the register file holds one tile
+// (14 values per pixel), so a CU runs load phase -> ten half sweeps -> store phase strictly one after the other — the load
+// phase streams its 11 planes at the HBM ceiling (~5 TB/s of unique bytes, 202 us of a 660-us launch at 1080p x 129 pairs,
+// profiles/round3/brox/) while the VALU idles, and the sweeps (567 us) leave the memory pipes idle.  Here 7 of the 11 planes
+// cross HBM during the sweeps; u, v, du, dv (du / dv are the previous launch's output) are still loaded at the tile's start.
+// Same per-pixel expressions in the same order as k_brox_sor_pk: bit-identical.
+// Barriers inside the tile loop are s_waitcnt lgkmcnt(0) + s_barrier by hand: __syncthreads() would also wait for the DMA in
+// flight (vmcnt), which is the very thing that must stay in flight.
+typedef __attribute__((address_space(3))) void brox_lds_void;
+typedef __attribute__((address_space(1))) const void brox_glb_void;
+__device__ __forceinline__ void brox_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int S>
+__global__ __launch_bounds__(1024) void k_brox_sor_stream(BroxLevelCtx c, int uv_set, int d_src, int n_sweeps, int tiles_x,
+                                                          int tiles_per_pair, int total_tiles) {
+    constexpr int TW = 64, TH = 64, HALO = 2 * S, NPF = 7;
+    enum { F_GX = 0, F_GY, F_IDU, F_IDV, F_ND, F_NU, F_NV };
+    __shared__ float WU[2][TH][TW / 2];
+    __shared__ float WV[2][TH][TW / 2];
+    __shared__ __attribute__((aligned(16))) float PF[NPF][TH][TW]; // the coefficient planes of the tile about to be swept
+#define WU_AT(ly, lx) WU[(lx)&1][ly][(lx) >> 1]
+#define WV_AT(ly, lx) WV[(lx)&1][ly][(lx) >> 1]
+    const int w = c.w, h = c.h, pitch = c.pitch;
+    const int pcol = threadIdx.x & 31, prow = threadIdx.x >> 5;
+    const int lx0 = 2 * pcol, ly0 = 2 * prow;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float omega = c.omega, om1 = 1.0f - omega;
+    constexpr int ROWS_PER_WAVE = 4;
+    const int band0 = (ly0 / ROWS_PER_WAVE) * ROWS_PER_WAVE;
+    const int xm = max(lx0 - 1, 0), xp = min(lx0 + 2, TW - 1), ym = max(ly0 - 1, 0), yp = min(ly0 + 2, TH - 1);
+
+    // tile number of this workgroup's i-th tile: rounds of gridDim.x tiles; inside a round the workgroups of one XCD (ids
+    // k, k + 8, ...: dfx_device.h) take one contiguous run, so the halos they share stay in one L2
+    const int G = (int)gridDim.x, per_xcd = G >> 3;
+    auto tile_of = [&](int i) -> int {
+        const int wg = (int)blockIdx.x;
+        return (G & 7) ? i * G + wg : i * G + (wg & 7) * per_xcd + (wg >> 3);
+    };
+    // LDS-DMA of the coefficient planes of a tile (BROX_PL_GX + q, q = 0..6: consecutive planes of the pair slot), 16 bytes per
+    // lane: one instruction copies four 64-float tile rows of a plane (lane = row l / 16, columns 4 (l % 16) .. + 3; the LDS
+    // side is wave-uniform base + 16 * lane = those rows back to back), wave `wave` takes rows 4 * wave .. + 3 of every
+    // plane: 7 instructions per wave and tile.  Rows outside the image read a clamped row; columns outside it are read where
+    // they would be (the row's padding, the neighbouring row, for row 0 the tail of the plane in front: all inside the pair
+    // slot, whose planes are sized for level 0 and start with u, v) — every such entry is masked when the values are taken
+    // out of LDS.  The source address is 8-byte aligned (tile origins are even).
+    static_assert(BROX_PL_GY == BROX_PL_GX + 1 && BROX_PL_NV == BROX_PL_GX + 6 && BROX_PL_GX > 0, "see above");
+    const float *pf_src = nullptr; // this lane's source in plane GX of the tile being fetched
+    auto pf_issue = [&](int t) {
+        const int b = t / tiles_per_pair, tile = t - b * tiles_per_pair;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x0 = tx * (TW - 2 * HALO) - HALO, y0 = ty * (TH - 2 * HALO) - HALO;
+        const int r = 4 * wave + (lane >> 4);
+        pf_src = bplane(c, b, BROX_PL_GX) + ((long long)min(max(y0 + r, 0), h - 1) * pitch + (x0 + 4 * (lane & 15)));
+#pragma unroll
+        for (int q = 0; q < NPF; ++q)
+            __builtin_amdgcn_global_load_lds((brox_glb_void *)(pf_src + (long long)q * c.plane_stride),
+                                             (brox_lds_void *)&PF[q][4 * wave][0], 16, 0, 0);
+    };
+
+    // u, v, du, dv of this thread's patch in tile t (two 8-byte loads per plane; rows / columns outside the image read element
+    // 0 and are masked when used): issued for tile i + 1 between tile i's last sweep and its stores, so that they are on their
+    // way while the stores go out
+    auto ld2 = [](const float *P, long long off) -> f2 { return *reinterpret_cast<const f2_a8 *>(P + off); };
+    f2 n_u[2], n_v[2], n_du[2], n_dv[2];
+    auto direct_loads = [&](int tt) {
+        const int b = tt / tiles_per_pair, tile = tt - b * tiles_per_pair;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x = tx * (TW - 2 * HALO) - HALO + lx0, y = ty * (TH - 2 * HALO) - HALO + ly0;
+        const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
+        const float *DU = bplane(c, b, du_plane(d_src)), *DV = bplane(c, b, dv_plane(d_src));
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long long o = (x >= 0 && x < w && y + k >= 0 && y + k < h) ? ((long long)(y + k) * pitch + x) : 0;
+            n_u[k] = ld2(u, o);
+            n_v[k] = ld2(v, o);
+            n_du[k] = ld2(DU, o);
+            n_dv[k] = ld2(DV, o);
+        }
+    };
+    int i = 0, t = tile_of(0);
+    if (t < total_tiles) {
+        pf_issue(t);
+        direct_loads(t);
+    }
+    for (; t < total_tiles; t = tile_of(++i)) {
+        const int b = t / tiles_per_pair, tile = t - b * tiles_per_pair;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x0 = tx * (TW - 2 * HALO) - HALO; // even
+        const int y0 = ty * (TH - 2 * HALO) - HALO; // even
+        const int x = x0 + lx0, y = y0 + ly0;       // pixel (row 0, column 0) of the patch
+        float *DUo = bplane(c, b, du_plane(d_src ^ 1)), *DVo = bplane(c, b, dv_plane(d_src ^ 1));
+        const bool inx0 = x >= 0 && x < w, inx1 = x + 1 >= 0 && x + 1 < w; // x is even: x < 0 puts both columns outside
+        const bool iny[3] = {y >= 0 && y < h, y + 1 >= 0 && y + 1 < h, y + 2 >= 0 && y + 2 < h};
+        auto mask = [&](f2 r, int k) -> f2 { return pk_set(inx0 && iny[k] ? r.x : 0.0f, inx1 && iny[k] ? r.y : 0.0f); };
+        // ---- what is not prefetched: u, v, du, dv of the patch, loaded since the end of the previous tile's sweeps
+        f2 r_u[2] = {n_u[0], n_u[1]}, r_v[2] = {n_v[0], n_v[1]}, r_du[2] = {n_du[0], n_du[1]}, r_dv[2] = {n_dv[0], n_dv[1]};
+        // ---- the coefficient planes have landed (this wave's DMA: vmcnt; every wave's: the barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        brox_lds_barrier();
+        auto pf2 = [&](int q, int k) -> f2 { return *reinterpret_cast<const f2_a8 *>(&PF[q][ly0 + k][lx0]); };
+        f2 r_gl[2], r_gd[2], r_idu[2], r_idv[2], r_nd[2], r_nu[2], r_nv[2];
+        float gxr[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            r_gl[k] = mask(pf2(F_GX, k), k);
+            r_gd[k] = mask(pf2(F_GY, k), k);
+            r_idu[k] = pf2(F_IDU, k);
+            r_idv[k] = pf2(F_IDV, k);
+            r_nd[k] = mask(pf2(F_ND, k), k);
+            r_nu[k] = mask(pf2(F_NU, k), k);
+            r_nv[k] = mask(pf2(F_NV, k), k);
+            // GX at x + 2.  In the tile's last patch column that is the next tile's pixel: the value only enters the update
+            // of a halo pixel, which nothing reads (k_brox_sor_pk loads it; any value gives the same owned region)
+            gxr[k] = PF[F_GX][ly0 + k][min(lx0 + 2, TW - 1)];
+            r_u[k] = mask(r_u[k], k);
+            r_v[k] = mask(r_v[k], k);
+            r_du[k] = mask(r_du[k], k);
+            r_dv[k] = mask(r_dv[k], k);
+        }
+        const f2 r_gy2 = *reinterpret_cast<const f2_a8 *>(&PF[F_GY][min(ly0 + 2, TH - 1)][lx0]); // (bottom patch row: as gxr)
+        f2 r_gr[2], r_gu[2], r_gs[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            r_gr[k] = pk_set(inx0 && iny[k] ? r_gl[k].y : 0.0f, (inx1 && iny[k] && x + 2 < w) ? gxr[k] : 0.0f);
+            if (k == 0)
+                r_gu[k] = pk_set(inx0 && iny[0] ? r_gd[1].x : 0.0f, inx1 && iny[0] ? r_gd[1].y : 0.0f);
+            else
+                r_gu[k] = pk_set(inx0 && iny[1] && iny[2] ? r_gy2.x : 0.0f, inx1 && iny[1] && iny[2] ? r_gy2.y : 0.0f);
+            r_gs[k] = ((r_gl[k] + r_gr[k]) + r_gd[k]) + r_gu[k];
+            const f2 den_u = r_idu[k] + r_gs[k], den_v = r_idv[k] + r_gs[k];
+            r_idu[k] = mask(pk_div_with_rcp((f2)(1.0f), den_u, pk_refined_rcp(den_u)), k);
+            r_idv[k] = mask(pk_div_with_rcp((f2)(1.0f), den_v, pk_refined_rcp(den_v)), k);
+            const f2 wu = r_u[k] + r_du[k], wv = r_v[k] + r_dv[k];
+            WU[0][ly0 + k][pcol] = wu.x, WU[1][ly0 + k][pcol] = wu.y;
+            WV[0][ly0 + k][pcol] = wv.x, WV[1][ly0 + k][pcol] = wv.y;
+        }
+#define BROX_PAIR(r) {pk_set(r[0].x, r[1].y), pk_set(r[0].y, r[1].x)}
+        const f2 gl[2] = BROX_PAIR(r_gl), gr[2] = BROX_PAIR(r_gr), gd[2] = BROX_PAIR(r_gd), gu[2] = BROX_PAIR(r_gu);
+        const f2 gs[2] = BROX_PAIR(r_gs), idu[2] = BROX_PAIR(r_idu), idv[2] = BROX_PAIR(r_idv), nd[2] = BROX_PAIR(r_nd);
+        const f2 nu[2] = BROX_PAIR(r_nu), nv[2] = BROX_PAIR(r_nv), uu[2] = BROX_PAIR(r_u), vv[2] = BROX_PAIR(r_v);
+        f2 du[2] = BROX_PAIR(r_du), dv[2] = BROX_PAIR(r_dv);
+#undef BROX_PAIR
+        brox_lds_barrier(); // W complete; every thread has taken its coefficients out of PF
+        if (tile_of(i + 1) < total_tiles)
+            pf_issue(tile_of(i + 1)); // its coefficient planes cross HBM during this tile's sweeps
+        for (int sw = 0; sw < n_sweeps; ++sw) {
+            const int m = 2 * (n_sweeps - 1 - sw) + 1;
+            const bool live = band0 + ROWS_PER_WAVE - 1 >= HALO - m && band0 < TH - HALO + m;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (live) {
+                    const int ax = lx0 + q, bx = lx0 + 1 - q;
+                    const int axl = q ? lx0 : xm, axr = q ? xp : lx0 + 1;
+                    const int bxl = q ? xm : lx0, bxr = q ? lx0 + 1 : xp;
+                    const f2 Lu = pk_set(WU_AT(ly0, axl), WU_AT(ly0 + 1, bxl)), Ru = pk_set(WU_AT(ly0, axr), WU_AT(ly0 + 1, bxr));
+                    const f2 Du = pk_set(WU_AT(ym, ax), WU_AT(ly0, bx)), Uu = pk_set(WU_AT(ly0 + 1, ax), WU_AT(yp, bx));
+                    const f2 Lv = pk_set(WV_AT(ly0, axl), WV_AT(ly0 + 1, bxl)), Rv = pk_set(WV_AT(ly0, axr), WV_AT(ly0 + 1, bxr));
+                    const f2 Dv = pk_set(WV_AT(ym, ax), WV_AT(ly0, bx)), Uv = pk_set(WV_AT(ly0 + 1, ax), WV_AT(yp, bx));
+                    const f2 su = (((gl[q] * Lu + gr[q] * Ru) + gd[q] * Du) + gu[q] * Uu) - gs[q] * uu[q];
+                    const f2 sv = (((gl[q] * Lv + gr[q] * Rv) + gd[q] * Dv) + gu[q] * Uv) - gs[q] * vv[q];
+                    const f2 du_n = om1 * du[q] + omega * (idu[q] * ((su - nu[q]) - nd[q] * dv[q]));
+                    const f2 dv_n = om1 * dv[q] + omega * (idv[q] * ((sv - nv[q]) - nd[q] * du_n));
+                    du[q] = du_n;
+                    dv[q] = dv_n;
+                    const f2 wu = uu[q] + du_n, wv = vv[q] + dv_n;
+                    WU_AT(ly0, ax) = wu.x;
+                    WU_AT(ly0 + 1, bx) = wu.y;
+                    WV_AT(ly0, ax) = wv.x;
+                    WV_AT(ly0 + 1, bx) = wv.y;
+                }
+                brox_lds_barrier();
+            }
+        }
+        if (tile_of(i + 1) < total_tiles)
+            direct_loads(tile_of(i + 1)); // (the coefficient registers are dead from here on)
+        // ---- store the owned region into the other du / dv set
+        if (lx0 >= HALO && lx0 < TW - HALO && x < w) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int ly = ly0 + k, yy = y + k;
+                if (ly >= HALO && ly < TH - HALO && yy < h) {
+                    const long long oo = (long long)yy * pitch + x;
+                    const f2 a = k == 0 ? pk_set(du[0].x, du[1].x) : pk_set(du[1].y, du[0].y);
+                    const f2 bq = k == 0 ? pk_set(dv[0].x, dv[1].x) : pk_set(dv[1].y, dv[0].y);
+                    if (x + 1 < w) {
+                        *reinterpret_cast<f2_a8 *>(DUo + oo) = a;
+                        *reinterpret_cast<f2_a8 *>(DVo + oo) = bq;
+                    } else {
+                        DUo[oo] = a.x;
+                        DVo[oo] = bq.x;
+                    }
+                }
+            }
+        }
+        // (the next tile's first barrier follows its own loads: W of this tile is no longer read by then — every wave
+        // has passed the last sweep barrier)
+    }
+#undef WU_AT
+#undef WV_AT
+}
+
 __global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int uv_set, int d_set) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -626,7 +833,14 @@ void brox_launch_sor_fused(hipStream_t s, const BroxLevelCtx &c, int uv_set, int
     constexpr int TW = 64, TH = 64, S = BROX_SWEEPS;
     const int tiles_x = (c.w + (TW - 4 * S) - 1) / (TW - 4 * S), tiles_y = (c.h + (TH - 4 * S) - 1) / (TH - 4 * S);
     const dim3 grid(tiles_x * tiles_y, 1, c.n_pairs), block(TW * TH / 4);
-    if (c.sor_progress)
+    const int total = tiles_x * tiles_y * c.n_pairs;
+    // one persistent workgroup per CU (a multiple of 8: the XCD-aware tile order needs whole rounds) where every CU gets at
+    // least four tiles; below that the static tile order leaves CUs idle that one workgroup per tile would have fed
+    if (c.sor_stream && total >= 4 * c.sor_stream) {
+        const int wgs = std::min(std::max(c.sor_stream / 8, 1) * 8, total);
+        hipLaunchKernelGGL((k_brox_sor_stream<S>), dim3(wgs), block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x,
+                           tiles_x * tiles_y, total);
+    } else if (c.sor_progress)
         hipLaunchKernelGGL((k_brox_sor_pk<S, 1>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);
     else
         hipLaunchKernelGGL((k_brox_sor_pk<S, 0>), grid, block, 0, s, c, uv_set, d_src, n_sweeps, tiles_x);

@@ -72,6 +72,7 @@ VAR_FARN_EVAL_ZERO_TAPS, VAR_FARN_POLY_ONE_ROW, VAR_FARN_M_IN_HBM = 0x04, 0x08, 
 VAR_TVL1_WARP_GATHER = 0x20
 VAR_TVL1_NO_HEAD = 0x40
 VAR_BROX_SOR_PROGRESS = 0x80
+VAR_BROX_SOR_PER_TILE = 0x100
 
 
 class DfxStats(C.Structure):

@@ -81,8 +81,9 @@ def test_large_pyramid_1080p(dfx, oracle):
 def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
     """The fused SOR kernel (LDS tile split by column parity, recomputed halo, five sweeps per launch, 8-byte loads, the
     two pixels of a half sweep as packed float2 math, exact Newton reciprocals) must not change a bit relative to the
-    simple one-launch-per-half-sweep form, for even and odd solver-iteration counts — in both of its synchronisation
-    forms: a workgroup barrier per half sweep (the default) and band-wise progress counters (round 6,
+    simple one-launch-per-half-sweep form, for even and odd solver-iteration counts — as persistent workgroups that
+    prefetch the next tile's coefficient planes by LDS-DMA while they sweep (round 6), as one workgroup per tile
+    (DFX_VAR_BROX_SOR_PER_TILE, rounds 2-5), and in both synchronisation forms of the latter: a workgroup barrier per half sweep (the default) and band-wise progress counters (round 6,
     DFX_VAR_BROX_SOR_PROGRESS: a wave waits for the two bands next to it, not for the workgroup; measured slower, kept)."""
     from denseflow_amd import engine as E
 
@@ -95,7 +96,7 @@ def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
         for solver in (10, 3, 7):
             with dfx.FlowEngine(w, h, "brox", impl=1, brox_solver_iterations=solver) as eng:
                 simple = eng.calc(f0, f1)
-            for variant in (0, E.VAR_BROX_SOR_PROGRESS):
+            for variant in (0, E.VAR_BROX_SOR_PER_TILE, E.VAR_BROX_SOR_PROGRESS):
                 with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver, variant=variant) as eng:
                     fused = eng.calc(f0, f1)
                     again = eng.calc(f0, f1)  # (a race between bands would not repeat itself)
