@@ -2,7 +2,7 @@
 # Round 6, closing run on the final tree: GPU suite, smoke, the default bench line, rocprofv3 --kernel-trace --stats of
 # bench.py per algorithm (the summaries roofline.avg_launch_us must agree with), the warp-and-head kernel against the
 # two-launch form (bench lines, per-dispatch timelines, SQ counters, HBM traffic), the Brox SOR's two synchronisation
-# forms (bench lines), every flow of the headline clip against the oracle.
+# forms and its streaming form (bench lines), every flow of the headline clip against the oracle.
 set -u
 R=$GRAFT_REPO_ROOT; O=gpurun_out/r6_final; mkdir -p $R/$O; export TMPDIR=/tmp
 cd $R; make -s host > $O/make_host.log 2>&1
@@ -41,10 +41,14 @@ done
 for a in farn brox; do nf=130; [ $a = brox ] && nf=66
   run fetch_$a $a $nf 0 FETCH_SIZE; run write_$a $a $nf 0 WRITE_SIZE
 done
-# Brox fused SOR: barrier (default) vs band-wise progress counters
-for rep in 1 2; do for v in 0 128; do
+# Brox fused SOR: streaming (default: persistent workgroups + LDS-DMA prefetch) vs one workgroup per tile (256) vs the latter
+# with band-wise progress counters instead of barriers (128)
+for rep in 1 2; do for v in 0 256 128; do
   python bench.py --algo brox --frames 131 --variant $v --steps 3 --warmup 1 --no-cpu-baseline --no-pcie --no-live-pmc --no-others > $O/brox_sync_v${v}_$rep.json 2>> $O/err.log
 done; done
+for v in 0 256; do
+  python bench.py --algo brox --width 3840 --height 2160 --frames 66 --step 2 --variant $v --steps 3 --warmup 1 --no-cpu-baseline --no-pcie --no-live-pmc --no-others > $O/brox_4k_v${v}.json 2>> $O/err.log
+done
 timeout 900 python scripts/round6/full_clip_parity.py 300 > $O/full_clip_parity.txt 2>> $O/err.log; cat $O/full_clip_parity.txt
 python - <<'PY'
 import json, glob
@@ -55,7 +59,7 @@ print({k:v for k,v in d["config"].items() if not isinstance(v,(dict,list,str))})
 print(d.get("cpu_baseline"))
 for a in ("farn","brox"):
     x=json.loads(open(f"{O}/bench_{a}_1080p.json").read().strip().splitlines()[-1]); print(a, x["value"], {k:v for k,v in x["roofline"].items() if k in ("bound","frac","traffic_frac","avg_launch_us")}, x.get("parity_check"))
-for f in sorted(glob.glob(O+"/head_ab_*.json"))+sorted(glob.glob(O+"/brox_sync_*.json")):
+for f in sorted(glob.glob(O+"/head_ab_*.json"))+sorted(glob.glob(O+"/brox_sync_*.json"))+sorted(glob.glob(O+"/brox_4k_v*.json")):
     x=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], round(x["value"],2), x.get("parity_check",{}).get("max_abs"))
 for v in (0,64):
     f=json.load(open(f"{O}/fetch_tvl1_v{v}.json")); w=json.load(open(f"{O}/write_tvl1_v{v}.json"))
