@@ -122,8 +122,9 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
         const int lxb = (int)fminf(fmaxf(fx0.y, -4.0f), (float)c.w + 4.0f) - tx0;
         const int lya = (int)fminf(fmaxf(fy0.x, -4.0f), (float)c.h + 4.0f) - ty0;
         const int lyb = (int)fminf(fmaxf(fy0.y, -4.0f), (float)c.h + 4.0f) - ty0;
-        const bool oka = lxa >= 0 && lxa + 3 < HD_TWL && lya >= 0 && lya + 3 < HD_THL;
-        const bool okb = lxb >= 0 && lxb + 3 < HD_TWL && lyb >= 0 && lyb + 3 < HD_THL;
+        // (0 <= l && l + 3 < N as one unsigned comparison)
+        const bool oka = (unsigned)lxa < (unsigned)(HD_TWL - 3) && (unsigned)lya < (unsigned)(HD_THL - 3);
+        const bool okb = (unsigned)lxb < (unsigned)(HD_TWL - 3) && (unsigned)lyb < (unsigned)(HD_THL - 3);
         far |= (ina && !oka ? 1u : 0u) << (2 * j);
         far |= (inb && !okb ? 1u : 0u) << (2 * j + 1);
         const int oa = oka ? lya * HD_TWL + lxa : 0, ob = okb ? lyb * HD_TWL + lxb : 0; // (outside the tile: redone below)
