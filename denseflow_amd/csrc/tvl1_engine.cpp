@@ -374,6 +374,12 @@ int Tvl1Engine::account(int nb) {
             useful = std::max(useful, h_checks[(b * DFX_LVL_MAX + s) * 2 + 1]);
         st.noop_steps += (uint64_t)std::max(0, launched_steps[s] - useful);
     }
+    int step_tiles[DFX_LVL_MAX] = {0}, head_tiles[DFX_LVL_MAX] = {0}; // workgroups per pair of the two launches of a step
+    for (int s = 0; s < nlevels && c->prm.impl == 0; ++s) {
+        const Tvl1LevelCtx x = level_ctx(s, 1);
+        step_tiles[s] = tvl1_step_blocks(x, 0);
+        head_tiles[s] = tvl1_head_blocks(x);
+    }
     for (int b = 0; b < nb; ++b) {
         for (int s = 0; s < nlevels; ++s) {
             const double px = (double)lv[s].w * lv[s].h;
@@ -382,11 +388,9 @@ int Tvl1Engine::account(int nb) {
                 it += h_iters[(b * DFX_LVL_MAX + s) * TVL1_MAX_WARPS + w];
             st.tvl1_total_iters += (uint64_t)it;
             st.tvl1_px_iters += px * (double)it;
-            if (c->prm.impl == 0) { // lane-iterations the tuned kernels executed: half rows x 32 lanes x tiles (tvl1_step_work)
-                Tvl1LevelCtx x = level_ctx(s, 1);
-                st.tvl1_lane_iters += 32.0 * ((double)h_work[(b * DFX_LVL_MAX + s) * 2 + 0] * tvl1_step_blocks(x, 0) +
-                                              (double)h_work[(b * DFX_LVL_MAX + s) * 2 + 1] * tvl1_head_blocks(x));
-            }
+            // lane-iterations the tuned kernels executed: half rows x 32 lanes x tiles (tvl1_ctrl.h: tvl1_step_work)
+            st.tvl1_lane_iters += 32.0 * ((double)h_work[(b * DFX_LVL_MAX + s) * 2 + 0] * step_tiles[s] +
+                                          (double)h_work[(b * DFX_LVL_MAX + s) * 2 + 1] * head_tiles[s]);
             st.algorithmic_bytes += px * (64.0 * (double)it + 44.0 * loop.warps + 28.0);
             st.step_algorithmic_bytes += px * (64.0 * (double)it + 44.0 * loop.warps);
         }
