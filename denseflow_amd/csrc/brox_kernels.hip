@@ -753,6 +753,9 @@ __global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int 
     v[o] = v[o] + bplane(c, b, dv_plane(d_set))[o];
 }
 
+// The bicubic weights of a window are separable and the same for u and v: they are formed once per pixel (<= 5 + 5
+// evaluations of brox_bicubic_w instead of up to 2 x 30), every tap's weight is still the single product w(x - cx) * w(y - cy)
+// and both sums still take their taps rows outer, columns inner: the same bits (round 6; the kernel was 4 % of Brox).
 __global__ __launch_bounds__(256) void k_brox_prolongate(BroxLevelCtx c, int uv_set, int dw, int dh, int dpitch,
                                                          float factor, float mul) {
     const DfxBlockXY blk = dfx_block_xy(); // XCD-aware (dfx_device.h): neighbouring rows share one L2
@@ -764,21 +767,28 @@ __global__ __launch_bounds__(256) void k_brox_prolongate(BroxLevelCtx c, int uv_
     const float y = (float)iy * factor, x = (float)ix * factor;
     const int y0 = max((int)ceilf(y - 2.0f), 0), y1 = min((int)floorf(y + 2.0f), sh - 1);
     const int x0 = max((int)ceilf(x - 2.0f), 0), x1 = min((int)floorf(x + 2.0f), sw - 1);
+    float wxs[5]; // [ceil(x - 2), floor(x + 2)] holds at most 5 integers
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float *src = bplane(c, b, BROX_PL_U0 + 2 * uv_set + k);
-        float sum = 0.f, wsum = 0.f;
-        for (int cy = y0; cy <= y1; ++cy) {
-            const float wy = brox_bicubic_w(y - (float)cy);
-            for (int cx = x0; cx <= x1; ++cx) {
-                const float wgt = brox_bicubic_w(x - (float)cx) * wy;
-                sum = sum + wgt * src[(long long)cy * c.pitch + cx];
+    for (int i = 0; i < 5; ++i)
+        wxs[i] = brox_bicubic_w(x - (float)(x0 + i));
+    const float *su = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *sv = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
+    float sum_u = 0.f, sum_v = 0.f, wsum = 0.f;
+    for (int cy = y0; cy <= y1; ++cy) {
+        const float wy = brox_bicubic_w(y - (float)cy);
+        const long long ro = (long long)cy * c.pitch + x0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (x0 + i <= x1) {
+                const float wgt = wxs[i] * wy;
+                sum_u = sum_u + wgt * su[ro + i];
+                sum_v = sum_v + wgt * sv[ro + i];
                 wsum = wsum + wgt;
             }
         }
-        const float val = (wsum == 0.0f) ? 0.0f : sum / wsum;
-        bplane(c, b, BROX_PL_U0 + 2 * (uv_set ^ 1) + k)[(long long)iy * dpitch + ix] = val * mul;
     }
+    const long long o = (long long)iy * dpitch + ix;
+    bplane(c, b, BROX_PL_U0 + 2 * (uv_set ^ 1))[o] = ((wsum == 0.0f) ? 0.0f : sum_u / wsum) * mul;
+    bplane(c, b, BROX_PL_V0 + 2 * (uv_set ^ 1))[o] = ((wsum == 0.0f) ? 0.0f : sum_v / wsum) * mul;
 }
 
 __global__ __launch_bounds__(256) void k_brox_merge(BroxLevelCtx c, int uv_set, float *out, long long out_stride) {
