@@ -44,6 +44,7 @@ class BroxEngine final : public AlgoEngine {
     float *d_planes = nullptr;
     long long plane_stride = 0, slot_stride = 0;
     PairDesc *d_pairs = nullptr, *h_pairs_pinned = nullptr;
+    float *d_sor_sink = nullptr; // BroxLevelCtx::sor_sink
     hipEvent_t ev[2] = {nullptr, nullptr};
     uint64_t batch_launches = 0;
 };
@@ -54,6 +55,7 @@ void BroxEngine::destroy() {
     dfx_free_host(h_slots_pinned);
     dfx_free_dev(d_planes);
     dfx_free_dev(d_pairs);
+    dfx_free_dev(d_sor_sink);
     dfx_free_host(h_pairs_pinned);
     for (auto &e : ev)
         if (e) {
@@ -106,6 +108,7 @@ int BroxEngine::create() {
         B /= 2;
     HIPCHK(c, hipMalloc(&d_planes, (size_t)slot_stride * B * sizeof(float)));
     HIPCHK(c, hipMalloc(&d_pairs, sizeof(PairDesc) * B));
+    HIPCHK(c, hipMalloc(&d_sor_sink, sizeof(float) * 16 * (size_t)std::max(n_cu, 1)));
     HIPCHK(c, hipHostMalloc(&h_pairs_pinned, sizeof(PairDesc) * B, hipHostMallocDefault));
     HIPCHK(c, hipEventCreateWithFlags(&ev[0], dfx_event_flags(c, true)));
     HIPCHK(c, hipEventCreateWithFlags(&ev[1], dfx_event_flags(c, true)));
@@ -170,6 +173,7 @@ BroxLevelCtx BroxEngine::level_ctx(int l, int nb) const {
     x.alpha = c->prm.brox_alpha;
     x.gamma = c->prm.brox_gamma;
     x.omega = 1.99f;
+    x.sor_sink = d_sor_sink;
     x.sor_progress = (c->prm.variant & DFX_VAR_BROX_SOR_PROGRESS) ? 1 : 0;
     x.sor_stream = (c->prm.variant & (DFX_VAR_BROX_SOR_PROGRESS | DFX_VAR_BROX_SOR_PER_TILE)) ? 0 : n_cu;
     return x;

@@ -30,6 +30,7 @@ struct BroxLevelCtx {
     float alpha, gamma, omega;
     int sor_stream;           // fused SOR: persistent workgroups (this many: the device's CUs) that prefetch the next tile's
                               // coefficient planes by LDS-DMA while they sweep (0: one workgroup per tile, DFX_VAR_BROX_SOR_PER_TILE)
+    float *sor_sink;          // streaming SOR: 16 floats per workgroup that take the stores of lanes owning nothing (see there)
     int sor_progress;         // fused SOR: band-wise progress counters (DFX_VAR_BROX_SOR_PROGRESS) instead of a barrier per half sweep
 };
 

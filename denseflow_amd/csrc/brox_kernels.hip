@@ -542,10 +542,21 @@ __global__ __launch_bounds__(1024) void k_brox_sor_pk(BroxLevelCtx c, int uv_set
 // (14 values per pixel), so a CU runs load phase -> ten half sweeps -> store phase strictly one after the other — the load
 // phase streams its 11 planes at the HBM ceiling (~5 TB/s of unique bytes, 202 us of a 660-us launch at 1080p x 129 pairs,
 // profiles/round3/brox/) while the VALU idles, and the sweeps (567 us) leave the memory pipes idle.  Here 7 of the 11 planes
-// cross HBM during the sweeps; u, v, du, dv (du / dv are the previous launch's output) are still loaded at the tile's start.
-// Same per-pixel expressions in the same order as k_brox_sor_pk: bit-identical.
-// Barriers inside the tile loop are s_waitcnt lgkmcnt(0) + s_barrier by hand: __syncthreads() would also wait for the DMA in
-// flight (vmcnt), which is the very thing that must stay in flight.
+// cross HBM during the sweeps; u, v, du, dv (du / dv are the previous launch's output) go into registers, their loads issued
+// BROX_SOR_EARLY_LOADS sweeps before the previous tile's end.  Same per-pixel operations in the same order as k_brox_sor_pk:
+// bit-identical.
+// Nothing in the tile loop waits for a counter to reach zero while something useful is in flight:
+//  * barriers are s_waitcnt lgkmcnt(0) + s_barrier by hand (__syncthreads() would also wait for vmcnt, i.e. for the DMA);
+//  * the DMA is the instruction by hand as well (see pf_issue), so that the compiler's own waits stay counted ones;
+//  * every wave issues exactly four stores per tile (lanes that own nothing store into a sink), so the tile's top can wait
+//    for "all but the four youngest operations": the loads and the DMA, not the acknowledgement of the stores.
+// Where a launch's time goes (level 0 at 1080p, 65 pairs, cycle counters of BROX_SOR_DEBUG == 3): sweeps 85 %, taking the
+// coefficients out of LDS + the divisions 7 %, top-of-tile wait and barrier 5 %, stores + DMA issue 4 %.  The sweeps run at
+// VALU 41 % / LDS 32 % busy — a barrier per half sweep with four waves per SIMD is latency-bound — and the DMA costs them
+// about a fifth (the launch without any DMA, wrong flows: 940 us against 1143): LABNOTES.md §11.
+#ifndef BROX_SOR_EARLY_LOADS
+#define BROX_SOR_EARLY_LOADS 3 // the next tile's u / v / du / dv loads are issued this many sweeps before the tile's end
+#endif                         // (measured at 1080p, pairs/s: 0 = after the sweeps 270, 1 274, 2 280, 3 280, 4 278, 5 272)
 typedef __attribute__((address_space(3))) void brox_lds_void;
 typedef __attribute__((address_space(1))) const void brox_glb_void;
 __device__ __forceinline__ void brox_lds_barrier() {
@@ -557,11 +568,12 @@ __global__ __launch_bounds__(1024) void k_brox_sor_stream(BroxLevelCtx c, int uv
                                                           int tiles_per_pair, int total_tiles) {
     constexpr int TW = 64, TH = 64, HALO = 2 * S, NPF = 7;
     enum { F_GX = 0, F_GY, F_IDU, F_IDV, F_ND, F_NU, F_NV };
-    __shared__ float WU[2][TH][TW / 2];
-    __shared__ float WV[2][TH][TW / 2];
+    // W = (u + du, v + dv) of the tile, the two values of a pixel side by side: a neighbour is ONE ds_read_b64 (2 LDS cycles per
+    // wave for both values; two ds_read_b32 are 4).  Columns are split by parity, as in k_brox_sor_pk: the 32 lanes of a lane
+    // group read 32 consecutive 8-byte elements = all 64 banks once.
+    __shared__ __attribute__((aligned(8))) f2 W[2][TH][TW / 2];
     __shared__ __attribute__((aligned(16))) float PF[NPF][TH][TW]; // the coefficient planes of the tile about to be swept
-#define WU_AT(ly, lx) WU[(lx)&1][ly][(lx) >> 1]
-#define WV_AT(ly, lx) WV[(lx)&1][ly][(lx) >> 1]
+#define W_AT(ly, lx) W[(lx)&1][ly][(lx) >> 1]
     const int w = c.w, h = c.h, pitch = c.pitch;
     const int pcol = threadIdx.x & 31, prow = threadIdx.x >> 5;
     const int lx0 = 2 * pcol, ly0 = 2 * prow;
@@ -571,6 +583,10 @@ __global__ __launch_bounds__(1024) void k_brox_sor_stream(BroxLevelCtx c, int uv
     const int band0 = (ly0 / ROWS_PER_WAVE) * ROWS_PER_WAVE;
     const int xm = max(lx0 - 1, 0), xp = min(lx0 + 2, TW - 1), ym = max(ly0 - 1, 0), yp = min(ly0 + 2, TH - 1);
 
+    auto tile_xy = [&](int k, int &tx, int &ty) { // (row by row.  Block by block — 8 x 4, 4 x 8, 6 x 6 tiles per XCD at a time, so
+        ty = k / tiles_x;                         // that halos are shared in L2 on both axes — measured the same to 0.5 %)
+        tx = k - ty * tiles_x;
+    };
     // tile number of this workgroup's i-th tile: rounds of gridDim.x tiles; inside a round the workgroups of one XCD (ids
     // k, k + 8, ...: dfx_device.h) take one contiguous run, so the halos they share stay in one L2
     const int G = (int)gridDim.x, per_xcd = G >> 3;
@@ -589,44 +605,66 @@ __global__ __launch_bounds__(1024) void k_brox_sor_stream(BroxLevelCtx c, int uv
     const float *pf_src = nullptr; // this lane's source in plane GX of the tile being fetched
     auto pf_issue = [&](int t) {
         const int b = t / tiles_per_pair, tile = t - b * tiles_per_pair;
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        int tx, ty;
+        tile_xy(tile, tx, ty);
         const int x0 = tx * (TW - 2 * HALO) - HALO, y0 = ty * (TH - 2 * HALO) - HALO;
         const int r = 4 * wave + (lane >> 4);
         pf_src = bplane(c, b, BROX_PL_GX) + ((long long)min(max(y0 + r, 0), h - 1) * pitch + (x0 + 4 * (lane & 15)));
+        // (the instruction by hand, not __builtin_amdgcn_global_load_lds: the compiler files that builtin as a FLAT access that
+        // may touch LDS, after which every vector-memory wait it inserts is vmcnt(0) until one has happened — and the tile
+        // loop's point is to never wait for its own stores.  The waits for the DMA are by hand anyway: top of the tile loop.)
+        const unsigned lds0 = (unsigned)(size_t)(brox_lds_void *)&PF[0][4 * wave][0];
 #pragma unroll
-        for (int q = 0; q < NPF; ++q)
-            __builtin_amdgcn_global_load_lds((brox_glb_void *)(pf_src + (long long)q * c.plane_stride),
-                                             (brox_lds_void *)&PF[q][4 * wave][0], 16, 0, 0);
+        for (int q = 0; q < NPF; ++q) {
+            const float *g = pf_src + (long long)q * c.plane_stride;
+            const unsigned l = __builtin_amdgcn_readfirstlane(lds0 + q * (unsigned)sizeof(PF[0]));
+            // M0 = the wave's LDS base; the s_nop is the wait state an LDS-DMA needs after a scalar write of M0 (the hazard
+            // recognizer does not look into inline assembly)
+            asm volatile("s_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "{m0}"(l) : "memory");
+        }
     };
 
     // u, v, du, dv of this thread's patch in tile t (two 8-byte loads per plane; rows / columns outside the image read element
-    // 0 and are masked when used): issued for tile i + 1 between tile i's last sweep and its stores, so that they are on their
-    // way while the stores go out
+    // 0 and are masked when used): issued for tile i + 1 BROX_SOR_EARLY_LOADS sweeps before tile i's last one — 16 more live
+    // registers through those sweeps (128 are in use either way), and the loads' latency is off the tile's critical path
     auto ld2 = [](const float *P, long long off) -> f2 { return *reinterpret_cast<const f2_a8 *>(P + off); };
     f2 n_u[2], n_v[2], n_du[2], n_dv[2];
-    auto direct_loads = [&](int tt) {
+    auto direct_loads = [&](int tt) { // (branch-free on purpose: see the stores at the end of the tile loop)
         const int b = tt / tiles_per_pair, tile = tt - b * tiles_per_pair;
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        int tx, ty;
+        tile_xy(tile, tx, ty);
         const int x = tx * (TW - 2 * HALO) - HALO + lx0, y = ty * (TH - 2 * HALO) - HALO + ly0;
         const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
         const float *DU = bplane(c, b, du_plane(d_src)), *DV = bplane(c, b, dv_plane(d_src));
+        const bool in_x = x >= 0 && x < w;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const long long o = (x >= 0 && x < w && y + k >= 0 && y + k < h) ? ((long long)(y + k) * pitch + x) : 0;
+            const int o = (in_x && y + k >= 0 && y + k < h) ? (y + k) * pitch + x : 0; // (a level's plane: < 2^31 elements)
             n_u[k] = ld2(u, o);
             n_v[k] = ld2(v, o);
             n_du[k] = ld2(DU, o);
             n_dv[k] = ld2(DV, o);
         }
     };
+    float *sink = c.sor_sink + 16 * (int)blockIdx.x;
     int i = 0, t = tile_of(0);
     if (t < total_tiles) {
         pf_issue(t);
         direct_loads(t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) // (the four stores a tile's loads are always followed by; apart, so that they stay four)
+            *reinterpret_cast<f2_a8 *>(sink + 4 * k) = pk_set(0.0f, 0.0f);
     }
+#if BROX_SOR_DEBUG == 3 // measurement build only: where workgroup 0's (and 77's) time goes, printed by the level-0 launches
+    long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
+#define BROX_TICK(k) (t1 = clock64(), tk[k] += t1 - t0, t0 = t1)
+#else
+#define BROX_TICK(k)
+#endif
     for (; t < total_tiles; t = tile_of(++i)) {
         const int b = t / tiles_per_pair, tile = t - b * tiles_per_pair;
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        int tx, ty;
+        tile_xy(tile, tx, ty);
         const int x0 = tx * (TW - 2 * HALO) - HALO; // even
         const int y0 = ty * (TH - 2 * HALO) - HALO; // even
         const int x = x0 + lx0, y = y0 + ly0;       // pixel (row 0, column 0) of the patch
@@ -636,9 +674,13 @@ __global__ __launch_bounds__(1024) void k_brox_sor_stream(BroxLevelCtx c, int uv
         auto mask = [&](f2 r, int k) -> f2 { return pk_set(inx0 && iny[k] ? r.x : 0.0f, inx1 && iny[k] ? r.y : 0.0f); };
         // ---- what is not prefetched: u, v, du, dv of the patch, loaded since the end of the previous tile's sweeps
         f2 r_u[2] = {n_u[0], n_u[1]}, r_v[2] = {n_v[0], n_v[1]}, r_du[2] = {n_du[0], n_du[1]}, r_dv[2] = {n_dv[0], n_dv[1]};
-        // ---- the coefficient planes have landed (this wave's DMA: vmcnt; every wave's: the barrier)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- the coefficient planes have landed (this wave's DMA: all but the four youngest operations, which are the
+        // previous tile's stores; every wave's: the barrier)
+        BROX_TICK(0);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        BROX_TICK(1);
         brox_lds_barrier();
+        BROX_TICK(2);
         auto pf2 = [&](int q, int k) -> f2 { return *reinterpret_cast<const f2_a8 *>(&PF[q][ly0 + k][lx0]); };
         f2 r_gl[2], r_gd[2], r_idu[2], r_idv[2], r_nd[2], r_nu[2], r_nv[2];
         float gxr[2];
@@ -673,72 +715,108 @@ __global__ __launch_bounds__(1024) void k_brox_sor_stream(BroxLevelCtx c, int uv
             r_idu[k] = mask(pk_div_with_rcp((f2)(1.0f), den_u, pk_refined_rcp(den_u)), k);
             r_idv[k] = mask(pk_div_with_rcp((f2)(1.0f), den_v, pk_refined_rcp(den_v)), k);
             const f2 wu = r_u[k] + r_du[k], wv = r_v[k] + r_dv[k];
-            WU[0][ly0 + k][pcol] = wu.x, WU[1][ly0 + k][pcol] = wu.y;
-            WV[0][ly0 + k][pcol] = wv.x, WV[1][ly0 + k][pcol] = wv.y;
+            W[0][ly0 + k][pcol] = pk_set(wu.x, wv.x), W[1][ly0 + k][pcol] = pk_set(wu.y, wv.y);
         }
 #define BROX_PAIR(r) {pk_set(r[0].x, r[1].y), pk_set(r[0].y, r[1].x)}
-        const f2 gl[2] = BROX_PAIR(r_gl), gr[2] = BROX_PAIR(r_gr), gd[2] = BROX_PAIR(r_gd), gu[2] = BROX_PAIR(r_gu);
+        f2 gl[2] = BROX_PAIR(r_gl), gr[2] = BROX_PAIR(r_gr), gd[2] = BROX_PAIR(r_gd), gu[2] = BROX_PAIR(r_gu);
         const f2 gs[2] = BROX_PAIR(r_gs), idu[2] = BROX_PAIR(r_idu), idv[2] = BROX_PAIR(r_idv), nd[2] = BROX_PAIR(r_nd);
         const f2 nu[2] = BROX_PAIR(r_nu), nv[2] = BROX_PAIR(r_nv), uu[2] = BROX_PAIR(r_u), vv[2] = BROX_PAIR(r_v);
         f2 du[2] = BROX_PAIR(r_du), dv[2] = BROX_PAIR(r_dv);
 #undef BROX_PAIR
         brox_lds_barrier(); // W complete; every thread has taken its coefficients out of PF
+        BROX_TICK(3);
+        // The previous tile's stores have had the whole consumption phase to be acknowledged; this wait (a builtin, so that
+        // the compiler's counter model sees it) makes it official, and the compiler has no reason left to wait for them —
+        // its counter would also count the DMA issued next, which it does not know about — anywhere in the sweeps.
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt and lgkmcnt left alone
+#if BROX_SOR_DEBUG != 6 // (6: measurement build only — no LDS-DMA after the first tile, WRONG flows)
         if (tile_of(i + 1) < total_tiles)
             pf_issue(tile_of(i + 1)); // its coefficient planes cross HBM during this tile's sweeps
-        for (int sw = 0; sw < n_sweeps; ++sw) {
+#endif
+#if BROX_SOR_DEBUG == 1 // measurement build only (scripts/build_variant.sh): everything but the sweeps (WRONG flows)
+        n_sweeps = 0;
+#endif
+        // The sweeps, in two runs with the next tile's direct loads between them.  (One loop with the loads under
+        // `sw == n_sweeps - BROX_SOR_EARLY_LOADS` makes the compiler assume they may be issued in several iterations: it then
+        // waits, vmcnt(3) in the middle of the sweeps, before it overwrites their destination registers, and that counter
+        // also counts the DMA in flight.  Measured: 1151 -> 1143 us per launch, i.e. the DMA had landed by then anyway.)
+        const int sw_split = max(n_sweeps - BROX_SOR_EARLY_LOADS, 0);
+        auto sweep = [&](int sw) {
             const int m = 2 * (n_sweeps - 1 - sw) + 1;
             const bool live = band0 + ROWS_PER_WAVE - 1 >= HALO - m && band0 < TH - HALO + m;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
+#if BROX_SOR_DEBUG == 4 // measurement build only: the barriers of the sweeps without their bodies (WRONG flows)
+                if (false) {
+#else
                 if (live) {
+#endif
                     const int ax = lx0 + q, bx = lx0 + 1 - q;
                     const int axl = q ? lx0 : xm, axr = q ? xp : lx0 + 1;
                     const int bxl = q ? xm : lx0, bxr = q ? lx0 + 1 : xp;
-                    const f2 Lu = pk_set(WU_AT(ly0, axl), WU_AT(ly0 + 1, bxl)), Ru = pk_set(WU_AT(ly0, axr), WU_AT(ly0 + 1, bxr));
-                    const f2 Du = pk_set(WU_AT(ym, ax), WU_AT(ly0, bx)), Uu = pk_set(WU_AT(ly0 + 1, ax), WU_AT(yp, bx));
-                    const f2 Lv = pk_set(WV_AT(ly0, axl), WV_AT(ly0 + 1, bxl)), Rv = pk_set(WV_AT(ly0, axr), WV_AT(ly0 + 1, bxr));
-                    const f2 Dv = pk_set(WV_AT(ym, ax), WV_AT(ly0, bx)), Uv = pk_set(WV_AT(ly0 + 1, ax), WV_AT(yp, bx));
-                    const f2 su = (((gl[q] * Lu + gr[q] * Ru) + gd[q] * Du) + gu[q] * Uu) - gs[q] * uu[q];
-                    const f2 sv = (((gl[q] * Lv + gr[q] * Rv) + gd[q] * Dv) + gu[q] * Uv) - gs[q] * vv[q];
-                    const f2 du_n = om1 * du[q] + omega * (idu[q] * ((su - nu[q]) - nd[q] * dv[q]));
-                    const f2 dv_n = om1 * dv[q] + omega * (idv[q] * ((sv - nv[q]) - nd[q] * du_n));
+                    // pixel A0 = (ly0, ax), pixel A1 = (ly0 + 1, bx).  The neighbour sums are formed per pixel on (u, v) pairs —
+                    // the weights are the same for both — and regrouped into (A0, A1) pairs for the coupled update; every
+                    // value goes through the same operations in the same order as in k_brox_sor_pk.
+                    const f2 L0 = W_AT(ly0, axl), R0 = W_AT(ly0, axr), D0 = W_AT(ym, ax), U0 = W_AT(ly0 + 1, ax);
+                    const f2 L1 = W_AT(ly0 + 1, bxl), R1 = W_AT(ly0 + 1, bxr), D1 = W_AT(ly0, bx), U1 = W_AT(yp, bx);
+                    // (the weights of a pixel enter as one half of their (A0, A1) register pair, selected by the multiply's
+                    // op_sel.  The empty asm hides from the optimiser that the pairs are loop invariants: it would hoist the
+                    // splat out of the sweep loop as a register pair of its own — 16 more registers, and spills.)
+                    asm volatile("" : "+v"(gl[q]), "+v"(gr[q]), "+v"(gd[q]), "+v"(gu[q]));
+#define BROX_SPLAT(r, c) pk_set(r[q].c, r[q].c)
+                    const f2 s0 = (((BROX_SPLAT(gl, x) * L0 + BROX_SPLAT(gr, x) * R0) + BROX_SPLAT(gd, x) * D0) + BROX_SPLAT(gu, x) * U0) -
+                                  BROX_SPLAT(gs, x) * pk_set(uu[q].x, vv[q].x);
+                    const f2 s1 = (((BROX_SPLAT(gl, y) * L1 + BROX_SPLAT(gr, y) * R1) + BROX_SPLAT(gd, y) * D1) + BROX_SPLAT(gu, y) * U1) -
+                                  BROX_SPLAT(gs, y) * pk_set(uu[q].y, vv[q].y);
+#undef BROX_SPLAT
+                    const f2 t0 = s0 - pk_set(nu[q].x, nv[q].x), t1 = s1 - pk_set(nu[q].y, nv[q].y); // (su - nu, sv - nv)
+                    const f2 tu = pk_set(t0.x, t1.x), tv = pk_set(t0.y, t1.y);
+                    const f2 du_n = om1 * du[q] + omega * (idu[q] * (tu - nd[q] * dv[q]));
+                    const f2 dv_n = om1 * dv[q] + omega * (idv[q] * (tv - nd[q] * du_n));
                     du[q] = du_n;
                     dv[q] = dv_n;
                     const f2 wu = uu[q] + du_n, wv = vv[q] + dv_n;
-                    WU_AT(ly0, ax) = wu.x;
-                    WU_AT(ly0 + 1, bx) = wu.y;
-                    WV_AT(ly0, ax) = wv.x;
-                    WV_AT(ly0 + 1, bx) = wv.y;
+                    W_AT(ly0, ax) = pk_set(wu.x, wv.x);
+                    W_AT(ly0 + 1, bx) = pk_set(wu.y, wv.y);
                 }
                 brox_lds_barrier();
             }
-        }
-        if (tile_of(i + 1) < total_tiles)
-            direct_loads(tile_of(i + 1)); // (the coefficient registers are dead from here on)
-        // ---- store the owned region into the other du / dv set
-        if (lx0 >= HALO && lx0 < TW - HALO && x < w) {
+        };
+        for (int sw = 0; sw < sw_split; ++sw)
+            sweep(sw);
+        direct_loads(min(tile_of(i + 1), total_tiles - 1)); // (after the last tile: a reload nobody uses — the shape is fixed)
+        for (int sw = sw_split; sw < n_sweeps; ++sw)
+            sweep(sw);
+        BROX_TICK(4);
+        // ---- store the owned region into the other du / dv set.  EVERY lane stores, exactly four instructions per wave: a
+        // lane that owns nothing stores into the workgroup's sink.  That fixed count is what lets the next tile wait for its
+        // loads with vmcnt(4) — the counter retires in issue order, so vmcnt(0) would also wait for these stores to be
+        // acknowledged by L2, once per tile (a workgroup per tile never waits for its stores: its waves just end).
+        // With an odd width the last column's 8-byte store puts its second half into the row's padding (pitch is w rounded up
+        // to 64), which every reader masks.
+        {
+            const bool own_x = lx0 >= HALO && lx0 < TW - HALO && x < w;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int ly = ly0 + k, yy = y + k;
-                if (ly >= HALO && ly < TH - HALO && yy < h) {
-                    const long long oo = (long long)yy * pitch + x;
-                    const f2 a = k == 0 ? pk_set(du[0].x, du[1].x) : pk_set(du[1].y, du[0].y);
-                    const f2 bq = k == 0 ? pk_set(dv[0].x, dv[1].x) : pk_set(dv[1].y, dv[0].y);
-                    if (x + 1 < w) {
-                        *reinterpret_cast<f2_a8 *>(DUo + oo) = a;
-                        *reinterpret_cast<f2_a8 *>(DVo + oo) = bq;
-                    } else {
-                        DUo[oo] = a.x;
-                        DVo[oo] = bq.x;
-                    }
-                }
+                const bool own = own_x && ly >= HALO && ly < TH - HALO && yy < h;
+                const long long oo = (long long)yy * pitch + x;
+                const f2 a = k == 0 ? pk_set(du[0].x, du[1].x) : pk_set(du[1].y, du[0].y);
+                const f2 bq = k == 0 ? pk_set(dv[0].x, dv[1].x) : pk_set(dv[1].y, dv[0].y);
+                *reinterpret_cast<f2_a8 *>(own ? DUo + oo : sink) = a;
+                *reinterpret_cast<f2_a8 *>(own ? DVo + oo : sink + 2) = bq;
             }
         }
         // (the next tile's first barrier follows its own loads: W of this tile is no longer read by then — every wave
         // has passed the last sweep barrier)
     }
-#undef WU_AT
-#undef WV_AT
+#if BROX_SOR_DEBUG == 3
+    if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == 77) && total_tiles > 50000)
+        printf("sor_stream wg %d tiles %d cycles: stores+issue %lld wait_vm %lld barrier %lld consume %lld sweeps %lld\n",
+               (int)blockIdx.x, i, tk[0], tk[1], tk[2], tk[3], tk[4]);
+#endif
+#undef BROX_TICK
+#undef W_AT
 }
 
 __global__ __launch_bounds__(256) void k_brox_add_increment(BroxLevelCtx c, int uv_set, int d_set) {
