@@ -104,6 +104,31 @@ def test_fused_sor_equals_one_launch_per_half_sweep(dfx, oracle):
                 assert np.array_equal(fused.view(np.uint32), again.view(np.uint32)), (w, h, solver, variant)
 
 
+def test_streaming_sor_odd_sizes_and_short_sweep_counts(dfx):
+    """The streaming form (k_brox_sor_stream) only runs where a launch has at least four tiles per CU, which the single pairs
+    of the test above never reach below 1080p: here six frames of an ODD-sized clip go through one FlowBuffer (5 pairs x 23 x 14
+    tiles = 1610 at level 0, 1035 at level 1), so that its special cases are on the path — the last column's 8-byte store whose
+    second half lands in the row's padding, tile rows and columns cut by the border, launches of 3 and 2 sweeps (fewer than the
+    three sweeps by which the next tile's loads run ahead), the sink stores of lanes that own nothing — and must not change
+    a bit relative to one workgroup per tile and to the one-launch-per-half-sweep form."""
+    from denseflow_amd import engine as E
+
+    w, h, n = 999, 601, 6
+    frames = SynthClip(w, h, 13).frames(n)
+    for solver in (10, 3, 7):
+        with dfx.FlowEngine(w, h, "brox", impl=1, brox_solver_iterations=solver, brox_outer_iterations=3, max_batch=n) as eng:
+            simple = eng.calc_optflows(frames, 1)
+        for variant in (0, E.VAR_BROX_SOR_PER_TILE):
+            with dfx.FlowEngine(w, h, "brox", brox_solver_iterations=solver, brox_outer_iterations=3, variant=variant,
+                                max_batch=n) as eng:
+                fused = eng.calc_optflows(frames, 1)
+                again = eng.calc_optflows(frames, 1)
+            assert len(fused) == n - 1
+            for i in range(n - 1):
+                assert np.array_equal(simple[i].view(np.uint32), fused[i].view(np.uint32)), (solver, variant, i)
+                assert np.array_equal(fused[i].view(np.uint32), again[i].view(np.uint32)), (solver, variant, i)
+
+
 @pytest.mark.parametrize("w,h,seed,t0,t1", [(224, 224, 1, 0, 8), (80, 56, 21, 0, 2), (40, 33, 4, 0, 3)])
 def test_mirror_index_fast_path_and_its_fallback(dfx, oracle, w, h, seed, t0, t1):
     """Round 5: stage 1's four mirror indices take ONE reflection when the bilinear window lies within one image size of
