@@ -152,8 +152,25 @@ __global__ __launch_bounds__(256) void k_brox_level_init(BroxLevelCtx c, int uv_
     }
 }
 
-struct BlTap { // 32-bit element offsets inside a level's plane (< 2^23 even at 3840x2160): the loads take the plane's
-    unsigned i00, i01, i10, i11; // uniform base pointer in scalar registers + zero-extended 32-bit lane offset: no 64-bit address math
+// Loads and stores at a 32-bit BYTE offset from a wave-uniform plane pointer: the instruction then takes the pointer from
+// scalar registers and the offset from one VGPR (global_load_dword v, v_off, s[base:base+1]).  With an ELEMENT offset the
+// byte offset is a 34-bit quantity as far as the compiler can tell, and every access pays a 64-bit shift and a 64-bit add on
+// the vector ALU (42 of stage 1's 437 vector instructions, round 6; 12 remain: where several planes are read at ONE offset the
+// optimiser forms one vector pointer and adds the planes' strides to it).  A level's plane is < 2^23 elements (3840 x 2160).
+typedef __attribute__((address_space(1))) char brox_glb_char;
+__device__ __forceinline__ brox_glb_char *opaque_base(const void *p) { // a wave-uniform pointer the optimiser cannot relate to another
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (brox_glb_char *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float ld_at(const float *p, unsigned byte_off) {
+    return *(const __attribute__((address_space(1))) float *)(opaque_base(p) + byte_off);
+}
+__device__ __forceinline__ void st_at(float *p, unsigned byte_off, float v) {
+    *(__attribute__((address_space(1))) float *)(opaque_base(p) + byte_off) = v;
+}
+struct BlTap {                   // byte offsets inside a level's plane (see ld_at)
+    unsigned i00, i01, i10, i11;
     float ax, ay;
 };
 __device__ __forceinline__ BlTap bl_setup(float fx, float fy, int w, int h, int pitch) {
@@ -172,22 +189,22 @@ __device__ __forceinline__ BlTap bl_setup(float fx, float fy, int w, int h, int 
         xa = mirror_idx_near(ix, w), xb = mirror_idx_near(ix + 1, w);
         ya = mirror_idx_near(iy, h), yb = mirror_idx_near(iy + 1, h);
     }
-    t.i00 = (unsigned)(ya * pitch + xa);
-    t.i01 = (unsigned)(ya * pitch + xb);
-    t.i10 = (unsigned)(yb * pitch + xa);
-    t.i11 = (unsigned)(yb * pitch + xb);
+    t.i00 = 4u * (unsigned)(ya * pitch + xa);
+    t.i01 = 4u * (unsigned)(ya * pitch + xb);
+    t.i10 = 4u * (unsigned)(yb * pitch + xa);
+    t.i11 = 4u * (unsigned)(yb * pitch + xb);
     return t;
 }
 __device__ __forceinline__ float bl_sample(const float *p, const BlTap &t) {
-    const float a = (1.0f - t.ax) * p[t.i00] + t.ax * p[t.i01];
-    const float b = (1.0f - t.ax) * p[t.i10] + t.ax * p[t.i11];
+    const float a = (1.0f - t.ax) * ld_at(p, t.i00) + t.ax * ld_at(p, t.i01);
+    const float b = (1.0f - t.ax) * ld_at(p, t.i10) + t.ax * ld_at(p, t.i11);
     return (1.0f - t.ay) * a + t.ay * b;
 }
 // two planes at once: the same three rounded operations per half (v_pk_mul / v_pk_add), same bits as bl_sample
 __device__ __forceinline__ f2 bl_sample2(const float *p, const float *q, const BlTap &t) {
     const f2 wx0 = (f2)(1.0f - t.ax), wx1 = (f2)(t.ax), wy0 = (f2)(1.0f - t.ay), wy1 = (f2)(t.ay);
-    const f2 a = wx0 * pk_set(p[t.i00], q[t.i00]) + wx1 * pk_set(p[t.i01], q[t.i01]);
-    const f2 b = wx0 * pk_set(p[t.i10], q[t.i10]) + wx1 * pk_set(p[t.i11], q[t.i11]);
+    const f2 a = wx0 * pk_set(ld_at(p, t.i00), ld_at(q, t.i00)) + wx1 * pk_set(ld_at(p, t.i01), ld_at(q, t.i01));
+    const f2 b = wx0 * pk_set(ld_at(p, t.i10), ld_at(q, t.i10)) + wx1 * pk_set(ld_at(p, t.i11), ld_at(q, t.i11));
     return wy0 * a + wy1 * b;
 }
 
@@ -206,37 +223,37 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set,
     const float *DU = bplane(c, b, du_plane(d_set)), *DV = bplane(c, b, dv_plane(d_set));
     for (int e = threadIdx.x; e < 6 * 66; e += 256) {
         const int ty = e / 66, tx = e - ty * 66;
-        const unsigned so = (unsigned)(min(max(y0 - 1 + ty, 0), h - 1) * pitch + min(max(x0 - 1 + tx, 0), w - 1));
-        WUs[ty][tx] = u[so] + DU[so];
-        WVs[ty][tx] = v[so] + DV[so];
+        const unsigned so = 4u * (unsigned)(min(max(y0 - 1 + ty, 0), h - 1) * pitch + min(max(x0 - 1 + tx, 0), w - 1));
+        WUs[ty][tx] = ld_at(u, so) + ld_at(DU, so);
+        WVs[ty][tx] = ld_at(v, so) + ld_at(DV, so);
     }
     __syncthreads();
     if (x >= w || y >= h)
         return;
     const PairDesc pd = c.pairs[b];
-    const unsigned o = (unsigned)(y * pitch + x); // 32-bit element offset inside the level's plane
+    const unsigned o = 4u * (unsigned)(y * pitch + x); // byte offset inside the level's plane (ld_at / st_at)
     // tile coordinates of (x, y) are (lx + 1, ly + 1); m / p = the clamped neighbours
 #define WU(dx, dy) WUs[ly + 1 + (dy)][lx + 1 + (dx)]
 #define WV(dx, dy) WVs[ly + 1 + (dy)][lx + 1 + (dx)]
-    const BlTap t = bl_setup((float)x + u[o], (float)y + v[o], w, h, pitch);
+    const BlTap t = bl_setup((float)x + ld_at(u, o), (float)y + ld_at(v, o), w, h, pitch);
     const f2 s01 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_I), fplane(c, pd.frame_b, BROX_FP_DX), t);
     const f2 s23 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_DY), fplane(c, pd.frame_b, BROX_FP_DXX), t);
     const f2 s45 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_DXY), fplane(c, pd.frame_b, BROX_FP_DYY), t);
     const float I1w = s01.x, Ixw = s01.y, Iyw = s23.x, Ixxw = s23.y, Ixyw = s45.x, Iyyw = s45.y;
-    const float Iz = I1w - fplane(c, pd.frame_a, BROX_FP_I)[o];
-    const float Ixz = Ixw - fplane(c, pd.frame_a, BROX_FP_DX)[o];
-    const float Iyz = Iyw - fplane(c, pd.frame_a, BROX_FP_DY)[o];
-    const float du = DU[o], dv = DV[o];
+    const float Iz = I1w - ld_at(fplane(c, pd.frame_a, BROX_FP_I), o);
+    const float Ixz = Ixw - ld_at(fplane(c, pd.frame_a, BROX_FP_DX), o);
+    const float Iyz = Iyw - ld_at(fplane(c, pd.frame_a, BROX_FP_DY), o);
+    const float du = ld_at(DU, o), dv = ld_at(DV, o);
     const float gamma = c.gamma;
     const float q0 = Iz + (Ixw * du + Iyw * dv);
     const float q1 = Ixz + (Ixxw * du + Ixyw * dv);
     const float q2 = Iyz + (Ixyw * du + Iyyw * dv);
     const float psi = (0.5f * inv_sqrtf_ieee((q0 * q0 + gamma * (q1 * q1 + q2 * q2)) + BROX_EPS2)) / c.alpha;
-    bplane(c, b, BROX_PL_NDUDV)[o] = psi * (Ixw * Iyw + gamma * (Ixxw * Ixyw + Ixyw * Iyyw));
-    bplane(c, b, BROX_PL_IDU)[o] = psi * (Ixw * Ixw + gamma * (Ixyw * Ixyw + Ixxw * Ixxw));
-    bplane(c, b, BROX_PL_IDV)[o] = psi * (Iyw * Iyw + gamma * (Ixyw * Ixyw + Iyyw * Iyyw));
-    bplane(c, b, BROX_PL_NU)[o] = psi * (Ixw * Iz + gamma * (Ixxw * Ixz + Ixyw * Iyz));
-    bplane(c, b, BROX_PL_NV)[o] = psi * (Iyw * Iz + gamma * (Iyyw * Iyz + Ixyw * Ixz));
+    st_at(bplane(c, b, BROX_PL_NDUDV), o, psi * (Ixw * Iyw + gamma * (Ixxw * Ixyw + Ixyw * Iyyw)));
+    st_at(bplane(c, b, BROX_PL_IDU), o, psi * (Ixw * Ixw + gamma * (Ixyw * Ixyw + Ixxw * Ixxw)));
+    st_at(bplane(c, b, BROX_PL_IDV), o, psi * (Iyw * Iyw + gamma * (Ixyw * Ixyw + Iyyw * Iyyw)));
+    st_at(bplane(c, b, BROX_PL_NU), o, psi * (Ixw * Iz + gamma * (Ixxw * Ixz + Ixyw * Iyz)));
+    st_at(bplane(c, b, BROX_PL_NV), o, psi * (Iyw * Iz + gamma * (Iyyw * Iyz + Ixyw * Ixz)));
     float gx = 0.0f, gy = 0.0f;
     if (x > 0) {
         const float ux = WU(0, 0) - WU(-1, 0), vx = WV(0, 0) - WV(-1, 0);
@@ -250,8 +267,8 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set,
         const float vx = 0.25f * (((WV(1, 0) + WV(1, -1)) - WV(-1, 0)) - WV(-1, -1));
         gy = 0.5f * inv_sqrtf_ieee((((ux * ux + uy * uy) + vx * vx) + vy * vy) + BROX_EPS2);
     }
-    bplane(c, b, BROX_PL_GX)[o] = gx;
-    bplane(c, b, BROX_PL_GY)[o] = gy;
+    st_at(bplane(c, b, BROX_PL_GX), o, gx);
+    st_at(bplane(c, b, BROX_PL_GY), o, gy);
 #undef WU
 #undef WV
 }

@@ -17,6 +17,31 @@ __device__ __forceinline__ float *pair_plane(const Tvl1LevelCtx &c, int pair, in
     return c.planes + (long long)pair * c.slot_stride + (long long)plane * c.plane_stride;
 }
 
+// Buffer addressing for the per-row accesses of the tile kernels (round 6).  A thread reads and writes its 8 tile rows in up to
+// 9 planes of its pair slot: through plain pointers every one of those accesses pays a 64-bit shift-and-add on the vector ALU
+// (plane base + 4 * element offset; the compiler's 1311 of the step kernel's 7612 static vector instructions, 2121 of the
+// warp-and-head kernel's 15 719) in kernels that are bound by vector-ALU issue.  A buffer instruction takes the slot's base from
+// a 128-bit descriptor in scalar registers, the plane's byte offset from ONE scalar register (soffset) and the pixel's byte
+// offset inside the plane from ONE 32-bit vector register: no vector instruction per access.  Offsets are bytes in 32 bits: the
+// engine refuses frame sizes whose pair slot reaches 4 GB (16 planes: beyond 8192 x 8192).  The descriptor's size field bounds
+// vector + scalar offset (measured on gfx950, scripts/round6/probe_buffer.py: the scalar offset IS part of the range check), so it is
+// set to the slot's size: every plane of the slot is in range, anything beyond it reads 0 / is not written.
+// Only dword accesses: this compiler's __builtin_amdgcn_raw_buffer_load_b128 emits a one-dword load and splats it.
+typedef __amdgpu_buffer_rsrc_t dfx_rsrc;
+__device__ __forceinline__ dfx_rsrc dfx_make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000); // raw buffer, 32-bit data
+}
+__device__ __forceinline__ dfx_rsrc pair_rsrc(const Tvl1LevelCtx &c, int pair) { // the pair's slot: plane q at soffset q * plane_bytes
+    return dfx_make_rsrc(c.planes + (long long)pair * c.slot_stride, (unsigned)(c.slot_stride * 4));
+}
+__device__ __forceinline__ unsigned plane_soff(const Tvl1LevelCtx &c, int plane) { return (unsigned)plane * (unsigned)(c.plane_stride * 4); }
+__device__ __forceinline__ float buf_ld(dfx_rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_st(dfx_rsrc r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
+}
+
 __device__ __forceinline__ double wave_reduce_sum_f64(double v) {
     // fixed butterfly order -> deterministic
 #pragma unroll

@@ -58,7 +58,9 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
     const float *I0 = c.frame_I + (long long)pd.frame_a * c.frame_stride + c.lvl_off;
     const long long fb = (long long)pd.frame_b * c.frame_stride + c.lvl_off;
     const float *P1 = c.frame_I + fb, *P1x = c.frame_Ix + fb, *P1y = c.frame_Iy + fb;
-    const float *u1p = pair_plane(c, b, PL_U1_0 + 2 * cur), *u2p = pair_plane(c, b, PL_U2_0 + 2 * cur);
+    // (buffer addressing, tvl1_device_common.h: the pair's slot, and a descriptor on this level's plane of frame a)
+    const dfx_rsrc rs = pair_rsrc(c, b), r0 = dfx_make_rsrc(I0, 4u * (unsigned)(c.pitch * c.h));
+    const unsigned s_u1 = plane_soff(c, PL_U1_0 + 2 * cur), s_u2 = plane_soff(c, PL_U2_0 + 2 * cur);
     float i0r[HP][2];
 #pragma unroll
     for (int j = 0; j < HP; ++j)
@@ -66,10 +68,10 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
         for (int e = 0; e < 2; ++e) {
             const int y = y0 + RM::row(role, j, e);
             const bool in = INTERIOR || (col_in && y >= 0 && y < c.h);
-            const long long o = in ? ((long long)y * c.pitch + x) : 0; // masked lanes read element 0
-            pf[3][j][e] = u1p[o];
-            pf[4][j][e] = u2p[o];
-            i0r[j][e] = I0[o];
+            const unsigned o = in ? 4u * (unsigned)(y * c.pitch + x) : 0u; // masked lanes read element 0
+            pf[3][j][e] = buf_ld(rs, o, s_u1);
+            pf[4][j][e] = buf_ld(rs, o, s_u2);
+            i0r[j][e] = buf_ld(r0, o, 0u);
         }
     const int tx0 = x0 - HD_HX, ty0 = y0 - HD_HY;
     float *t1 = tile, *tgx = tile + HD_THL * HD_TWL, *tgy = tgx + HD_THL * HD_TWL;
@@ -83,6 +85,7 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
         const long long ro = (long long)min(max(ty0 + r, 0), c.h - 1) * c.pitch;
         const int gx = tx0 + 4 * q;
         const int lx4 = min(max(gx, 0), ((c.w - 1) >> 2) << 2); // aligned, inside the row
+        // (plain pointers: this compiler's __builtin_amdgcn_raw_buffer_load_b128 emits a ONE-dword load and splats it)
         const float4 a = *reinterpret_cast<const float4 *>(P1 + ro + lx4);
         const float4 bq = *reinterpret_cast<const float4 *>(P1x + ro + lx4);
         const float4 cq = *reinterpret_cast<const float4 *>(P1y + ro + lx4);
@@ -194,18 +197,19 @@ __device__ __forceinline__ void head_load_p(const Tvl1LevelCtx &c, int b, int cu
     const int lane = threadIdx.x & 63, role = RM::who();
     const int x = x0 + lane;
     const bool col_in = INTERIOR || (x >= 0 && x < c.w);
-    const float *g[4] = {pair_plane(c, b, PL_P11_0 + 4 * cur), pair_plane(c, b, PL_P12_0 + 4 * cur),
-                         pair_plane(c, b, PL_P21_0 + 4 * cur), pair_plane(c, b, PL_P22_0 + 4 * cur)};
+    const dfx_rsrc rs = pair_rsrc(c, b);
+    const unsigned so[4] = {plane_soff(c, PL_P11_0 + 4 * cur), plane_soff(c, PL_P12_0 + 4 * cur),
+                            plane_soff(c, PL_P21_0 + 4 * cur), plane_soff(c, PL_P22_0 + 4 * cur)};
 #pragma unroll
     for (int j = 0; j < HP; ++j)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int y = y0 + RM::row(role, j, e);
             const bool in = INTERIOR || (col_in && y >= 0 && y < c.h);
-            const long long o = in ? ((long long)y * c.pitch + x) : 0;
+            const unsigned o = in ? 4u * (unsigned)(y * c.pitch + x) : 0u;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                pf[5 + q][j][e] = g[q][o];
+                pf[5 + q][j][e] = buf_ld(rs, o, so[q]);
         }
 }
 
@@ -219,17 +223,18 @@ __device__ __forceinline__ void head_store_warp(const Tvl1LevelCtx &c, int b, in
     const int gx = x0 + lx;
     const bool col_in = INTERIOR || (gx >= 0 && gx < c.w);
     const bool col_owned = (lx >= K || own_lo) && (lx < HD_TW - K || own_hi) && col_in;
-    float *o_wx = pair_plane(c, b, PL_I1WX), *o_wy = pair_plane(c, b, PL_I1WY), *o_rc = pair_plane(c, b, PL_RHOC);
+    const dfx_rsrc rs = pair_rsrc(c, b);
+    const unsigned s_wx = plane_soff(c, PL_I1WX), s_wy = plane_soff(c, PL_I1WY), s_rc = plane_soff(c, PL_RHOC);
 #pragma unroll
     for (int j = 0; j < HP; ++j)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int ly = RM::row(role, j, e), gy = y0 + ly;
             if (col_owned && ly >= K && ly < HD_TH - K && (INTERIOR || (gy >= 0 && gy < c.h))) {
-                const long long o = (long long)gy * c.pitch + gx;
-                o_wx[o] = e ? T.kwx[j].y : T.kwx[j].x;
-                o_wy[o] = e ? T.kwy[j].y : T.kwy[j].x;
-                o_rc[o] = e ? T.krc[j].y : T.krc[j].x;
+                const unsigned o = 4u * (unsigned)(gy * c.pitch + gx);
+                buf_st(rs, o, s_wx, e ? T.kwx[j].y : T.kwx[j].x);
+                buf_st(rs, o, s_wy, e ? T.kwy[j].y : T.kwy[j].x);
+                buf_st(rs, o, s_rc, e ? T.krc[j].y : T.krc[j].x);
             }
         }
 }
