@@ -221,8 +221,16 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set,
     const int b = blockIdx.z, w = c.w, h = c.h, pitch = c.pitch;
     const float *u = bplane(c, b, BROX_PL_U0 + 2 * uv_set), *v = bplane(c, b, BROX_PL_V0 + 2 * uv_set);
     const float *DU = bplane(c, b, du_plane(d_set)), *DV = bplane(c, b, dv_plane(d_set));
-    for (int e = threadIdx.x; e < 6 * 66; e += 256) {
-        const int ty = e / 66, tx = e - ty * 66;
+    // the tile: every thread its own pixel (coordinates clamped to the image: what a neighbour inside the image reads there),
+    // threads 0 .. 139 one entry of the 1-pixel ring each (rows 0 and 5: 2 x 66, columns 0 and 65 of rows 1 .. 4: 8)
+    const unsigned oc = 4u * (unsigned)(min(y, h - 1) * pitch + min(x, w - 1));
+    const float u_c = ld_at(u, oc), v_c = ld_at(v, oc), du_c = ld_at(DU, oc), dv_c = ld_at(DV, oc);
+    WUs[ly + 1][lx + 1] = u_c + du_c;
+    WVs[ly + 1][lx + 1] = v_c + dv_c;
+    if (threadIdx.x < 140) {
+        const int e = (int)threadIdx.x, k = e - 132;
+        const int ty = e < 66 ? 0 : (e < 132 ? 5 : 1 + (k & 3));
+        const int tx = e < 66 ? e : (e < 132 ? e - 66 : (k < 4 ? 0 : 65));
         const unsigned so = 4u * (unsigned)(min(max(y0 - 1 + ty, 0), h - 1) * pitch + min(max(x0 - 1 + tx, 0), w - 1));
         WUs[ty][tx] = ld_at(u, so) + ld_at(DU, so);
         WVs[ty][tx] = ld_at(v, so) + ld_at(DV, so);
@@ -231,11 +239,11 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set,
     if (x >= w || y >= h)
         return;
     const PairDesc pd = c.pairs[b];
-    const unsigned o = 4u * (unsigned)(y * pitch + x); // byte offset inside the level's plane (ld_at / st_at)
+    const unsigned o = oc; // byte offset inside the level's plane (ld_at / st_at): inside the image oc is the pixel's own
     // tile coordinates of (x, y) are (lx + 1, ly + 1); m / p = the clamped neighbours
 #define WU(dx, dy) WUs[ly + 1 + (dy)][lx + 1 + (dx)]
 #define WV(dx, dy) WVs[ly + 1 + (dy)][lx + 1 + (dx)]
-    const BlTap t = bl_setup((float)x + ld_at(u, o), (float)y + ld_at(v, o), w, h, pitch);
+    const BlTap t = bl_setup((float)x + u_c, (float)y + v_c, w, h, pitch);
     const f2 s01 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_I), fplane(c, pd.frame_b, BROX_FP_DX), t);
     const f2 s23 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_DY), fplane(c, pd.frame_b, BROX_FP_DXX), t);
     const f2 s45 = bl_sample2(fplane(c, pd.frame_b, BROX_FP_DXY), fplane(c, pd.frame_b, BROX_FP_DYY), t);
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void k_brox_stage1(BroxLevelCtx c, int uv_set,
     const float Iz = I1w - ld_at(fplane(c, pd.frame_a, BROX_FP_I), o);
     const float Ixz = Ixw - ld_at(fplane(c, pd.frame_a, BROX_FP_DX), o);
     const float Iyz = Iyw - ld_at(fplane(c, pd.frame_a, BROX_FP_DY), o);
-    const float du = ld_at(DU, o), dv = ld_at(DV, o);
+    const float du = du_c, dv = dv_c;
     const float gamma = c.gamma;
     const float q0 = Iz + (Ixw * du + Iyw * dv);
     const float q1 = Ixz + (Ixxw * du + Ixyw * dv);

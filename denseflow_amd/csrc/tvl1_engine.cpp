@@ -166,6 +166,9 @@ int Tvl1Engine::create() {
     const long long plane = (long long)lv[0].pitch * c->H;
     plane_stride = plane;
     slot_stride = plane_stride * PL_COUNT;
+    // the tile kernels address a pair slot with 32-bit byte offsets behind a buffer descriptor (tvl1_device_common.h)
+    if ((unsigned long long)slot_stride * sizeof(float) >= (1ull << 32))
+        return dfx_fail(c, DFX_ERR_INVALID, "tvl1: frame too large (a pair's 16 work planes must stay below 4 GB: about 8192 x 8192)");
     B = p.max_batch;
     if (B <= 0) {
         const long long px0 = (long long)c->W * c->H;
