@@ -42,6 +42,21 @@ __device__ __forceinline__ void buf_st(dfx_rsrc r, unsigned voff, unsigned soff,
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 
+// The level context of a kernel whose FIRST parameter is a Tvl1LevelCtx by value, read from the kernel-argument segment at the
+// point of use — for the ONCE-PER-LEVEL paths (finish_level, the in-kernel warp phase of the non-default configurations).  A
+// by-value parameter is loaded into scalar registers once, at the top; the fields only those paths need then live across the
+// whole kernel, and the step kernel, short of scalar registers, parks them in VGPR lanes (v_writelane / v_readlane: vector-ALU
+// instructions, in a kernel bound by vector-ALU issue).  Behind this reference such a path loads them (s_load, scalar cache)
+// when it runs; the empty asm makes the pointer opaque, so the compiler cannot turn the loads back into a use of the parameter.
+// Measured (scripts/round6/r6_gpu39.sh): step kernel 105 -> 86 lane writes, 250 -> 152 lane reads (static), 501.4 vs 496.4 pairs/s.
+// NOT for the hot phases: the same trick in front of the store phase and the epilogue is 2 % slower (LABNOTES section 11) — the
+// scalar loads then sit on every wave's path, and in the warp-and-head kernel it made the spilling worse.
+__device__ __forceinline__ const Tvl1LevelCtx &dfx_kernarg_ctx() {
+    auto p = (const __attribute__((address_space(4))) Tvl1LevelCtx *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const Tvl1LevelCtx *)p;
+}
+
 __device__ __forceinline__ double wave_reduce_sum_f64(double v) {
     // fixed butterfly order -> deterministic
 #pragma unroll
