@@ -131,12 +131,15 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
         far |= (ina && !oka ? 1u : 0u) << (2 * j);
         far |= (inb && !okb ? 1u : 0u) << (2 * j + 1);
         const int oa = oka ? lya * HD_TWL + lxa : 0, ob = okb ? lyb * HD_TWL + lxb : 0; // (outside the tile: redone below)
+        // every weight's arm chosen by the tap's position in the window (pk_bicubic_window: half the instructions of the
+        // select chain); a pixel for which that is not the chain's choice (one-ulp coincidences, NaN / infinite flows) is
+        // redone below with the scalar chain, like one whose window leaves the tile
         f2 cwx[4], cwy[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cwx[k] = pk_bicubic_coeff(wx - (fx0 + (float)k));
-            cwy[k] = pk_bicubic_coeff(wy - (fy0 + (float)k));
-        }
+        bool wxa, wxb, wya, wyb;
+        pk_bicubic_window(wx, fx0, cwx, wxa, wxb);
+        pk_bicubic_window(wy, fy0, cwy, wya, wyb);
+        far |= (ina && !(wxa && wya) ? 1u : 0u) << (2 * j);
+        far |= (inb && !(wxb && wyb) ? 1u : 0u) << (2 * j + 1);
         f2 sum = (f2)(0.0f), sumx = (f2)(0.0f), sumy = (f2)(0.0f), wsum = (f2)(0.0f);
 #pragma unroll
         for (int jy = 0; jy < 4; ++jy) {
