@@ -74,7 +74,10 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
             i0r[j][e] = buf_ld(r0, o, 0u);
         }
     const int tx0 = x0 - HD_HX, ty0 = y0 - HD_HY;
-    float *t1 = tile, *tgx = tile + HD_THL * HD_TWL, *tgy = tgx + HD_THL * HD_TWL;
+    // LDS image tile: (I1, I1x) of a pixel side by side — a tap of the bicubic sums is one ds_read_b64 for both (2 LDS cycles per
+    // wave instead of 4: the warp phase keeps the LDS nearly as busy as the vector ALU) — and I1y as a plane of its own
+    f2 *t1x = reinterpret_cast<f2 *>(tile);
+    float *tgy = tile + 2 * HD_THL * HD_TWL;
     // image tiles: float4 q of tile row r covers image columns tx0 + 4q .. + 3 of row clamp(ty0 + r); clamp-to-edge is
     // applied here, so a tile entry IS the point-sampled texture value (k_tvl1_warp_lds has the same copy loop): a float4
     // left of the image is column 0 four times, one right of it column w - 1, one that straddles the right border is patched
@@ -91,8 +94,8 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
         const float4 cq = *reinterpret_cast<const float4 *>(P1y + ro + lx4);
         const int o = r * HD_TWL + 4 * q;
         if (gx >= 0 && gx + 3 <= c.w - 1) { // (the image tile is wider than the iteration tile INTERIOR speaks about)
-            *reinterpret_cast<float4 *>(&t1[o]) = a;
-            *reinterpret_cast<float4 *>(&tgx[o]) = bq;
+            *reinterpret_cast<float4 *>(&t1x[o]) = make_float4(a.x, bq.x, a.y, bq.y);
+            *reinterpret_cast<float4 *>(&t1x[o + 2]) = make_float4(a.z, bq.z, a.w, bq.w);
             *reinterpret_cast<float4 *>(&tgy[o]) = cq;
             continue;
         }
@@ -100,8 +103,8 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int k = min(max(gx + e, 0), c.w - 1) - lx4; // 0..3: the element of the loaded float4 column gx + e clamps to
-            t1[o + e] = k == 0 ? av[0] : k == 1 ? av[1] : k == 2 ? av[2] : av[3];
-            tgx[o + e] = k == 0 ? bv[0] : k == 1 ? bv[1] : k == 2 ? bv[2] : bv[3];
+            t1x[o + e] = pk_set(k == 0 ? av[0] : k == 1 ? av[1] : k == 2 ? av[2] : av[3],
+                                k == 0 ? bv[0] : k == 1 ? bv[1] : k == 2 ? bv[2] : bv[3]);
             tgy[o + e] = k == 0 ? cv[0] : k == 1 ? cv[1] : k == 2 ? cv[2] : cv[3];
         }
     }
@@ -140,19 +143,22 @@ __device__ __forceinline__ void head_warp(const Tvl1LevelCtx &c, int b, int cur,
         pk_bicubic_window(wy, fy0, cwy, wya, wyb);
         far |= (ina && !(wxa && wya) ? 1u : 0u) << (2 * j);
         far |= (inb && !(wxb && wyb) ? 1u : 0u) << (2 * j + 1);
-        f2 sum = (f2)(0.0f), sumx = (f2)(0.0f), sumy = (f2)(0.0f), wsum = (f2)(0.0f);
+        // (I1, I1x) sums per pixel (sa: pixel a, sb: pixel b; the weight enters as one half of wgt, by op_sel), I1y sums and
+        // the weight sum for both pixels at once: per value the same products and additions in the same order as before
+        f2 sa = (f2)(0.0f), sb = (f2)(0.0f), sumy = (f2)(0.0f), wsum = (f2)(0.0f);
 #pragma unroll
         for (int jy = 0; jy < 4; ++jy) {
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) {
                 const int o = jy * HD_TWL + jx;
                 const f2 wgt = cwx[jx] * cwy[jy];
-                sum = sum + wgt * pk_set(t1[oa + o], t1[ob + o]);
-                sumx = sumx + wgt * pk_set(tgx[oa + o], tgx[ob + o]);
+                sa = sa + pk_set(wgt.x, wgt.x) * t1x[oa + o];
+                sb = sb + pk_set(wgt.y, wgt.y) * t1x[ob + o];
                 sumy = sumy + wgt * pk_set(tgy[oa + o], tgy[ob + o]);
                 wsum = wsum + wgt;
             }
         }
+        const f2 sum = pk_set(sa.x, sb.x), sumx = pk_set(sa.y, sb.y);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const float coeff = 1.0f / (e ? wsum.y : wsum.x);
